@@ -1,0 +1,283 @@
+"""MI355X-native rigid-body physics stepper — Python host mirror of the C-ABI in include/mi_physics.h.
+
+`World` exposes the reference engine's physics call shapes (study-game-engines/directx-renderer-kurth, src/physics/physics.h:
+collider_component::as*, rigid_body_component(kinematic, gravityFactor, linearDamping, angularDamping),
+add*ConstraintFromGlobalPoints, getConstraint, physicsStep(scene, arena, timer, settings, dt)) over libmi_physics.so,
+the same way the reference's own Python side binds its Physics-Lib DLL with ctypes (learning/loco_env.py:7-45).
+There is no CPU fallback: without the compiled HIP library or without a GPU, constructing a World raises.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmi_physics.so")
+
+STATIC = 0xFFFFFFFF
+SPHERE, CAPSULE, CYLINDER, AABB, OBB, HULL = range(6)
+DISTANCE, BALL, FIXED, HINGE, CONE_TWIST, SLIDER = range(6)
+CONSTRAINT_POD_BYTES = (28, 24, 40, 104, 120, 72)
+
+COLLIDER_DTYPE = np.dtype([("shape", "<f4", 10), ("restitution", "<f4"), ("friction", "<f4"), ("density", "<f4"),
+                           ("type", "<u4"), ("objectType", "<u4"), ("objectIndex", "<u4")])
+CONTACT_DTYPE = np.dtype([("point", "<f4", 3), ("depth", "<f4"), ("normal", "<f4", 3), ("friction_restitution", "<u4")])
+
+
+class Material(C.Structure):
+    _fields_ = [("restitution", C.c_float), ("friction", C.c_float), ("density", C.c_float)]
+
+
+class Settings(C.Structure):
+    """physics_settings (reference physics.h:382-397) minus the std::function callbacks."""
+    _fields_ = [("fixedFrameRate", C.c_uint32), ("frameRate", C.c_uint32), ("maxPhysicsIterationsPerFrame", C.c_uint32),
+                ("numRigidSolverIterations", C.c_uint32), ("numClothVelocityIterations", C.c_uint32),
+                ("numClothPositionIterations", C.c_uint32), ("numClothDriftIterations", C.c_uint32),
+                ("simdBroadPhase", C.c_uint32), ("simdNarrowPhase", C.c_uint32), ("simdConstraintSolver", C.c_uint32)]
+
+    def __init__(self, **kw):
+        super().__init__(1, 120, 4, 30, 0, 1, 0, 1, 1, 1)
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+class WorldDesc(C.Structure):
+    _fields_ = [("device", C.c_int32), ("reserveBodies", C.c_uint32), ("reserveColliders", C.c_uint32), ("reservePairs", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("numRigidBodies", C.c_uint32), ("numColliders", C.c_uint32), ("numBroadphaseOverlaps", C.c_uint32), ("numCollisions", C.c_uint32),
+                ("numContacts", C.c_uint32), ("numColors", C.c_uint32), ("numJoints", C.c_uint32), ("numInternalSteps", C.c_uint32),
+                ("msCollidersBroad", C.c_float), ("msNarrow", C.c_float), ("msSolverSetup", C.c_float), ("msSolve", C.c_float),
+                ("msIntegrate", C.c_float), ("msTotal", C.c_float)]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTED_SYMBOLS = [
+    "mi_world_create", "mi_world_destroy", "mi_last_error", "mi_add_body", "mi_add_collider", "mi_add_static_collider",
+    "mi_add_distance_constraint_local", "mi_add_distance_constraint_global", "mi_add_ball_constraint_local", "mi_add_ball_constraint_global",
+    "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
+    "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_apply_force_torque", "mi_set_velocity",
+    "mi_set_transform", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
+    "mi_get_stats", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_debug_num_pairs", "mi_debug_read_pairs",
+    "mi_debug_read_world_colliders", "mi_debug_num_manifold_slots", "mi_debug_read_manifolds", "mi_debug_num_colors", "mi_debug_read_schedule",
+    "mi_debug_read_joint_order", "mi_debug_read_body_state",
+]
+
+
+def build(force=False):
+    """Compile libmi_physics.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j6"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the C-ABI library.  Raises if it has not been built — there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError("libmi_physics.so is missing: run __graft_entry__.build() (hipcc) first; there is no CPU fallback")
+        lib = C.CDLL(_LIB_PATH)
+        lib.mi_world_create.restype = C.c_void_p
+        lib.mi_last_error.restype = C.c_char_p
+        for name in EXPORTED_SYMBOLS:
+            fn = getattr(lib, name)
+            if name.startswith("mi_add_") or name in ("mi_num_bodies", "mi_num_colliders", "mi_debug_num_pairs", "mi_debug_num_manifold_slots", "mi_debug_num_colors"):
+                fn.restype = C.c_uint32
+        _lib = lib
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class PhysicsError(RuntimeError):
+    pass
+
+
+class World:
+    """One physics world on one MI355X.  Method names follow the reference's free functions / component factories."""
+
+    def __init__(self, device=-1, reserve_bodies=0, reserve_colliders=0, reserve_pairs=0):
+        self.lib = load_library()
+        desc = WorldDesc(device, reserve_bodies, reserve_colliders, reserve_pairs)
+        h = self.lib.mi_world_create(C.byref(desc))
+        if not h:
+            raise PhysicsError("mi_world_create failed: %s" % (self.lib.mi_last_error(None) or b"").decode())
+        self.w = C.c_void_p(h)
+        self.timer = C.c_float(0.0)
+
+    def close(self):
+        if getattr(self, "w", None):
+            self.lib.mi_world_destroy(self.w)
+            self.w = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, code):
+        if code:
+            raise PhysicsError("mi_physics error %d: %s" % (code, (self.lib.mi_last_error(self.w) or b"").decode()))
+
+    def _id(self, v):
+        if v == 0xFFFFFFFF:
+            raise PhysicsError((self.lib.mi_last_error(self.w) or b"invalid id").decode())
+        return v
+
+    # ---- add API ------------------------------------------------------------------------------------------
+    def add_body(self, pos, rot=(0, 0, 0, 1), kinematic=False, gravity_factor=1.0, linear_damping=0.4, angular_damping=0.4):
+        return self._id(self.lib.mi_add_body(self.w, int(kinematic), C.c_float(gravity_factor), C.c_float(linear_damping), C.c_float(angular_damping), _f(pos), _f(rot)))
+
+    def add_collider(self, body, ctype, shape, material):
+        s = np.zeros(10, np.float32); s[:len(shape)] = shape
+        m = Material(*material)
+        return self._id(self.lib.mi_add_collider(self.w, C.c_uint32(body), C.c_uint32(ctype), _f(s), C.byref(m)))
+
+    def add_static_collider(self, ctype, shape, material, pos=(0, 0, 0), rot=(0, 0, 0, 1)):
+        s = np.zeros(10, np.float32); s[:len(shape)] = shape
+        m = Material(*material)
+        return self._id(self.lib.mi_add_static_collider(self.w, C.c_uint32(ctype), _f(s), C.byref(m), _f(pos), _f(rot)))
+
+    def add_distance_constraint_local(self, a, b, la, lb, distance):
+        return self._id(self.lib.mi_add_distance_constraint_local(self.w, a, b, _f(la), _f(lb), C.c_float(distance)))
+
+    def add_distance_constraint_global(self, a, b, ga, gb):
+        return self._id(self.lib.mi_add_distance_constraint_global(self.w, a, b, _f(ga), _f(gb)))
+
+    def add_ball_constraint_local(self, a, b, la, lb):
+        return self._id(self.lib.mi_add_ball_constraint_local(self.w, a, b, _f(la), _f(lb)))
+
+    def add_ball_constraint_global(self, a, b, g):
+        return self._id(self.lib.mi_add_ball_constraint_global(self.w, a, b, _f(g)))
+
+    def add_fixed_constraint_global(self, a, b, g):
+        return self._id(self.lib.mi_add_fixed_constraint_global(self.w, a, b, _f(g)))
+
+    def add_hinge_constraint_global(self, a, b, anchor, axis, min_limit=1.0, max_limit=-1.0):
+        return self._id(self.lib.mi_add_hinge_constraint_global(self.w, a, b, _f(anchor), _f(axis), C.c_float(min_limit), C.c_float(max_limit)))
+
+    def add_cone_twist_constraint_global(self, a, b, anchor, axis, swing_limit, twist_limit):
+        return self._id(self.lib.mi_add_cone_twist_constraint_global(self.w, a, b, _f(anchor), _f(axis), C.c_float(swing_limit), C.c_float(twist_limit)))
+
+    def add_slider_constraint_global(self, a, b, anchor, axis, min_limit=1.0, max_limit=-1.0):
+        return self._id(self.lib.mi_add_slider_constraint_global(self.w, a, b, _f(anchor), _f(axis), C.c_float(min_limit), C.c_float(max_limit)))
+
+    def constraint_get(self, ctype, cid, nbytes=None):
+        buf = np.zeros(nbytes or CONSTRAINT_POD_BYTES[ctype], np.uint8)
+        self._check(self.lib.mi_constraint_get(self.w, ctype, cid, _p(buf)))
+        return buf
+
+    def constraint_set(self, ctype, cid, buf):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        self._check(self.lib.mi_constraint_set(self.w, ctype, cid, _p(buf)))
+
+    def delete_constraint(self, ctype, cid):
+        self._check(self.lib.mi_delete_constraint(self.w, ctype, cid))
+
+    def apply_force_torque(self, body, force, torque=(0, 0, 0)):
+        self._check(self.lib.mi_apply_force_torque(self.w, body, _f(force), _f(torque)))
+
+    def set_velocity(self, body, lin, ang=(0, 0, 0)):
+        self._check(self.lib.mi_set_velocity(self.w, body, _f(lin), _f(ang)))
+
+    # ---- stepping -------------------------------------------------------------------------------------------
+    def step(self, dt, settings=None):
+        """physicsStep(scene, arena, timer, settings, dt) — reference physics.h:405."""
+        settings = settings or Settings()
+        self._check(self.lib.mi_step(self.w, C.byref(self.timer), C.byref(settings), C.c_float(dt)))
+
+    def step_internal(self, dt, iterations=30):
+        """One physicsStepInternal (reference physics.cpp:1180-1362) at exactly dt."""
+        self._check(self.lib.mi_step_internal(self.w, C.c_float(dt), C.c_uint32(iterations)))
+
+    def synchronize(self):
+        self._check(self.lib.mi_synchronize(self.w))
+
+    def enable_stage_timing(self, on=True):
+        self._check(self.lib.mi_enable_stage_timing(self.w, int(on)))
+
+    # ---- results --------------------------------------------------------------------------------------------
+    @property
+    def num_bodies(self):
+        return self.lib.mi_num_bodies(self.w)
+
+    @property
+    def num_colliders(self):
+        return self.lib.mi_num_colliders(self.w)
+
+    def transforms(self, which=1):
+        out = np.zeros((self.num_bodies, 7), np.float32)
+        self._check(self.lib.mi_read_transforms(self.w, C.c_uint32(which), _p(out), C.c_uint32(len(out))))
+        return out
+
+    def velocities(self):
+        out = np.zeros((self.num_bodies, 6), np.float32)
+        self._check(self.lib.mi_read_velocities(self.w, _p(out), C.c_uint32(len(out))))
+        return out
+
+    def mass_properties(self):
+        out = np.zeros((self.num_bodies, 13), np.float32)
+        self._check(self.lib.mi_read_mass_properties(self.w, _p(out), C.c_uint32(len(out))))
+        return out
+
+    def stats(self):
+        s = Stats()
+        self._check(self.lib.mi_get_stats(self.w, C.byref(s)))
+        return s.asdict()
+
+    def device_pointers(self):
+        pose, vel, stream = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self.lib.mi_device_pointers(self.w, C.byref(pose), C.byref(vel), C.byref(stream)))
+        return pose.value, vel.value, stream.value
+
+    # ---- inspection of the last internal step (parity tests) -------------------------------------------------------
+    def pairs(self):
+        out = np.zeros((self.lib.mi_debug_num_pairs(self.w), 2), np.uint32)
+        if len(out):
+            self._check(self.lib.mi_debug_read_pairs(self.w, _p(out)))
+        return out
+
+    def world_colliders(self):
+        n = self.num_colliders
+        cols = np.zeros(n, COLLIDER_DTYPE); aabbs = np.zeros((n, 6), np.float32)
+        self._check(self.lib.mi_debug_read_world_colliders(self.w, _p(cols), _p(aabbs)))
+        return cols, aabbs
+
+    def manifolds(self):
+        """(ordered collider pairs [n,2], counts [n], contacts [n,4] CONTACT_DTYPE, body pairs [n,2]) per candidate pair slot."""
+        n = self.lib.mi_debug_num_manifold_slots(self.w)
+        pairs = np.zeros((n, 2), np.uint32); counts = np.zeros(n, np.uint32); contacts = np.zeros((n, 4), CONTACT_DTYPE); bp = np.zeros((n, 2), np.uint32)
+        if n:
+            self._check(self.lib.mi_debug_read_manifolds(self.w, _p(pairs), _p(counts), _p(contacts), _p(bp)))
+        return pairs, counts, contacts, bp
+
+    def schedule(self):
+        """(manifold slots in Gauss-Seidel execution order, colour start offsets [66])."""
+        cs = np.zeros(66, np.uint32)
+        n = self.lib.mi_debug_num_manifold_slots(self.w)
+        slots = np.zeros(max(n, 1), np.uint32)
+        self._check(self.lib.mi_debug_read_schedule(self.w, _p(slots), _p(cs)))
+        return slots[:int(cs[65])], cs
+
+    def joint_order(self, ctype, n):
+        out = np.zeros(max(n, 1), np.uint32)
+        self._check(self.lib.mi_debug_read_joint_order(self.w, ctype, _p(out)))
+        return out[:n]
+
+    def body_state(self):
+        n = self.num_bodies + 1
+        cog = np.zeros((n, 4), np.float32); inv = np.zeros((n, 12), np.float32)
+        self._check(self.lib.mi_debug_read_body_state(self.w, _p(cog), _p(inv), C.c_uint32(n)))
+        return cog, inv

@@ -1,0 +1,208 @@
+// Per-body and per-collider streaming kernels: world-space collider build (reference physics.cpp:631-756),
+// applyGravityAndIntegrateForces (rigid_body.cpp:95-124), integrateVelocity (rigid_body.cpp:126-142) and the
+// physics_transform0/1 copies + interpolation of physicsStep (physics.cpp:1375-1378, 1396-1402).
+// All HBM-bound, one thread per element, float4 (16 B/lane) accesses.
+#include "world.h"
+
+#define GRAVITY -9.81f // reference physics.h:11
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1: world-space colliders + AABBs.  Reads 64 B local collider + 32 B pose, writes 64 B world collider + 2x16 B AABB.
+// ---------------------------------------------------------------------------------------------------------------
+MI_DEV void growBox(V3& mn, V3& mx, V3 o) { mn = vmin(mn, o); mx = vmax(mx, o); }
+
+// bounding_box::transformToAABB (bounding_volumes.cpp:58-70): 8 corners in this order.
+MI_DEV void boxToAABB(V3 lo, V3 hi, Q4 rot, V3 tr, V3& mn, V3& mx)
+{
+	mn = v3s(MI_FLT_MAX); mx = v3s(-MI_FLT_MAX);
+	growBox(mn, mx, rot * lo + tr);
+	growBox(mn, mx, rot * v3(hi.x, lo.y, lo.z) + tr);
+	growBox(mn, mx, rot * v3(lo.x, hi.y, lo.z) + tr);
+	growBox(mn, mx, rot * v3(hi.x, hi.y, lo.z) + tr);
+	growBox(mn, mx, rot * v3(lo.x, lo.y, hi.z) + tr);
+	growBox(mn, mx, rot * v3(hi.x, lo.y, hi.z) + tr);
+	growBox(mn, mx, rot * v3(lo.x, hi.y, hi.z) + tr);
+	growBox(mn, mx, rot * hi + tr);
+}
+
+__global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
+	const float4* __restrict__ colStaticPose, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nc) return;
+	ColliderRec c = colLocal[i];
+	u32 type = colType(c), body = colBody(c);
+	const float4* P = (body < nb) ? (pose + 2 * body) : (colStaticPose + 2 * i);
+	V3 tpos = v3f4(P[0]);
+	Q4 trot = q4f4(P[1]);
+	V3 mn, mx;
+	ColliderRec o = c;
+	switch (type)
+	{
+		case MI_SPHERE:
+		{
+			V3 center = tpos + trot * v3(c.a.x, c.a.y, c.a.z);
+			float r = c.a.w;
+			mn = center - v3s(r); mx = center + v3s(r);
+			o.a = make_float4(center.x, center.y, center.z, r);
+		} break;
+		case MI_CAPSULE:
+		case MI_CYLINDER: // cylinders are stored but their pair kernels are not built yet (they never reach the narrowphase)
+		{
+			V3 posA = trot * v3(c.a.x, c.a.y, c.a.z) + tpos;
+			V3 posB = trot * v3(c.a.w, c.b.x, c.b.y) + tpos;
+			float r = c.b.z;
+			V3 r3 = v3s(r);
+			mn = v3s(MI_FLT_MAX); mx = v3s(-MI_FLT_MAX);
+			growBox(mn, mx, posA + r3); growBox(mn, mx, posA - r3); growBox(mn, mx, posB + r3); growBox(mn, mx, posB - r3);
+			o.a = make_float4(posA.x, posA.y, posA.z, posB.x);
+			o.b = make_float4(posB.y, posB.z, r, 0.f);
+		} break;
+		case MI_AABB:
+		{
+			V3 lo = v3(c.a.x, c.a.y, c.a.z), hi = v3(c.a.w, c.b.x, c.b.y);
+			boxToAABB(lo, hi, trot, tpos, mn, mx);
+			if (trot.x == 0.f && trot.y == 0.f && trot.z == 0.f && trot.w == 1.f)
+			{
+				o.a = make_float4(mn.x, mn.y, mn.z, mx.x);
+				o.b = make_float4(mx.y, mx.z, 0.f, 0.f);
+			}
+			else // a rotated AABB becomes an OBB (physics.cpp:725-733)
+			{
+				V3 center = trot * ((lo + hi) * 0.5f) + tpos;
+				V3 radius = (hi - lo) * 0.5f;
+				o.a = make_float4(trot.x, trot.y, trot.z, trot.w);
+				o.b = make_float4(center.x, center.y, center.z, radius.x);
+				o.c.x = radius.y; o.c.y = radius.z;
+				o.d.x = __uint_as_float((u32)MI_OBB);
+			}
+		} break;
+		case MI_OBB:
+		{
+			Q4 q = q4f4(c.a);
+			V3 center = v3(c.b.x, c.b.y, c.b.z);
+			V3 radius = v3(c.b.w, c.c.x, c.c.y);
+			Q4 wq = trot * q;                         // bounding_oriented_box::transformToAABB/OBB (bounding_volumes.cpp:127-142)
+			V3 wc = trot * center + tpos;
+			boxToAABB(-radius, radius, wq, wc, mn, mx);
+			o.a = make_float4(wq.x, wq.y, wq.z, wq.w);
+			o.b = make_float4(wc.x, wc.y, wc.z, radius.x);
+		} break;
+		default: mn = v3s(0.f); mx = v3s(0.f); break;
+	}
+	colWorld[i] = o;
+	aabbMin[i] = make_float4(mn.x, mn.y, mn.z, 0.f);
+	aabbMax[i] = make_float4(mx.x, mx.y, mx.z, 0.f);
+}
+
+void launch_build_colliders(World& w)
+{
+	if (!w.nc) return;
+	hipLaunchKernelGGL(k_build_colliders, dim3((w.nc + 255) / 256), dim3(256), 0, w.stream, w.nc, w.nb, w.colLocal.p, w.pose.p, w.colStaticPose.p,
+		w.colWorld.p, w.aabbMin.p, w.aabbMax.p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K8: gravity + force integration, world inertia.  140 B read + 104 B write per body.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, const float4* __restrict__ pose, const float4* __restrict__ bprops,
+	const float4* __restrict__ force, float4* __restrict__ vel, float4* __restrict__ cog, float4* __restrict__ invIw)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > nb) return;
+	if (i == nb) // static dummy (physics.cpp:1279)
+	{
+		float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+		vel[2 * i] = z; vel[2 * i + 1] = z; cog[i] = z; invIw[3 * i] = z; invIw[3 * i + 1] = z; invIw[3 * i + 2] = z;
+		return;
+	}
+	V3 pos = v3f4(pose[2 * i]);
+	Q4 rot = q4f4(pose[2 * i + 1]);
+	float4 p0 = bprops[5 * i], c0 = bprops[5 * i + 1], c1 = bprops[5 * i + 2], c2 = bprops[5 * i + 3], p4 = bprops[5 * i + 4];
+	V3 localCOG = v3f4(p0); float invMass = p0.w;
+	M3 I; I.m00 = c0.x; I.m10 = c0.y; I.m20 = c0.z; I.m01 = c1.x; I.m11 = c1.y; I.m21 = c1.z; I.m02 = c2.x; I.m12 = c2.y; I.m22 = c2.z;
+	float gravityFactor = p4.x, linDamp = p4.y, angDamp = p4.z;
+
+	V3 gpos = pos + rot * localCOG;
+	M3 R = quaternionToMat3(rot);
+	M3 Iw = R * I * mtranspose(R);
+
+	V3 F = v3f4(force[2 * i]), T = v3f4(force[2 * i + 1]);
+	if (invMass > 0.f) { F.y += (GRAVITY / invMass * gravityFactor); }
+	V3 linAcc = F * invMass;
+	V3 angAcc = Iw * T;
+	float4 lv = vel[2 * i], av = vel[2 * i + 1];
+	V3 v = v3f4(lv), wv = v3f4(av);
+	v += linAcc * dt;
+	wv += angAcc * dt;
+	v *= 1.f / (1.f + dt * linDamp);
+	wv *= 1.f / (1.f + dt * angDamp);
+
+	vel[2 * i] = make_float4(v.x, v.y, v.z, invMass);
+	vel[2 * i + 1] = make_float4(wv.x, wv.y, wv.z, 0.f);
+	cog[i] = make_float4(gpos.x, gpos.y, gpos.z, invMass);
+	invIw[3 * i] = make_float4(Iw.m00, Iw.m10, Iw.m20, 0.f);
+	invIw[3 * i + 1] = make_float4(Iw.m01, Iw.m11, Iw.m21, 0.f);
+	invIw[3 * i + 2] = make_float4(Iw.m02, Iw.m12, Iw.m22, 0.f);
+}
+
+void launch_integrate_forces(World& w, float dt)
+{
+	hipLaunchKernelGGL(k_integrate_forces, dim3((w.nb + 1 + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.force.p,
+		w.vel.p, w.cog.p, w.invIw.p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K13: velocity integration.  Reads cog(16) + vel(32) + rot(16) + localCOG(16), writes pose(32) + clears accumulators.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_integrate_velocities(u32 nb, float dt, float4* __restrict__ pose, const float4* __restrict__ bprops,
+	const float4* __restrict__ vel, const float4* __restrict__ cog, float4* __restrict__ force)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nb) return;
+	Q4 grot = q4f4(pose[2 * i + 1]);
+	V3 gpos = v3f4(cog[i]);
+	V3 v = v3f4(vel[2 * i]), wv = v3f4(vel[2 * i + 1]);
+	V3 localCOG = v3f4(bprops[5 * i]);
+	Q4 deltaRot = q4(0.5f * wv.x, 0.5f * wv.y, 0.5f * wv.z, 0.f);
+	deltaRot = deltaRot * grot;
+	Q4 rotation = qnormalize(q4(grot.x + deltaRot.x * dt, grot.y + deltaRot.y * dt, grot.z + deltaRot.z * dt, grot.w + deltaRot.w * dt));
+	V3 position = gpos + v * dt;
+	V3 epos = position - rotation * localCOG;
+	pose[2 * i] = make_float4(epos.x, epos.y, epos.z, 0.f);
+	pose[2 * i + 1] = make_float4(rotation.x, rotation.y, rotation.z, rotation.w);
+	float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+	force[2 * i] = z; force[2 * i + 1] = z;
+}
+
+void launch_integrate_velocities(World& w, float dt)
+{
+	if (!w.nb) return;
+	hipLaunchKernelGGL(k_integrate_velocities, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.vel.p, w.cog.p, w.force.p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// physicsStep's transform0 <- transform1 copy and the lerp(transform0, transform1, t) write-back.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lerp_pose(u32 nb, float t, const float4* __restrict__ p0, const float4* __restrict__ p1, float4* __restrict__ out)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nb) return;
+	float4 a = p0[2 * i], b = p1[2 * i];
+	out[2 * i] = make_float4(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z), 0.f);
+	float4 l = p0[2 * i + 1], u = p1[2 * i + 1];
+	Q4 q = qnormalize(q4(l.x + t * (u.x - l.x), l.y + t * (u.y - l.y), l.z + t * (u.z - l.z), l.w + t * (u.w - l.w)));
+	out[2 * i + 1] = make_float4(q.x, q.y, q.z, q.w);
+}
+
+void launch_copy_pose0(World& w)
+{
+	if (!w.nb) return;
+	MI_CHECK(hipMemcpyAsync(w.pose0.p, w.pose.p, sizeof(float4) * 2 * w.nb, hipMemcpyDeviceToDevice, w.stream));
+}
+
+void launch_lerp_pose(World& w, float t)
+{
+	if (!w.nb) return;
+	hipLaunchKernelGGL(k_lerp_pose, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, t, w.pose0.p, w.pose.p, w.poseLerp.p);
+}

@@ -1,0 +1,225 @@
+// Broadphase: the set of collider pairs whose world AABBs overlap inclusively (reference aabbVsAABB,
+// bounding_volumes.h:352-358) — the same SET the reference's sort-and-sweep (collision_broad.cpp:297-447) reports.
+// MI355X design: a hashed uniform grid instead of a serial sweep.  Cell edge = largest extent of any collider attached to a
+// rigid body (so an AABB spans at most 2 cells per axis and all partners live in the 27 neighbouring cells); colliders larger
+// than a cell (static ground planes) go to a short "large" list that every collider tests directly.  Colliders are radix-sorted
+// by cell hash (rocPRIM), cell ranges come from boundary detection, and pairs are produced by a count pass + exclusive scan +
+// write pass so the pair list has a deterministic order without atomics.
+#include "world.h"
+#include <rocprim/rocprim.hpp>
+
+#define CELL_BIAS (1 << 20)
+#define CELL_MASK ((1u << 21) - 1u)
+#define EMPTY_CELL 0xFFFFFFFFu
+
+MI_DEV u64 packCell(i32 ix, i32 iy, i32 iz) { return ((u64)(u32)(ix & CELL_MASK)) | ((u64)(u32)(iy & CELL_MASK) << 21) | ((u64)(u32)(iz & CELL_MASK) << 42); }
+MI_DEV u32 hashCell(u64 k, u32 mask)
+{
+	k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull; k ^= k >> 27; k *= 0x94d049bb133111ebull; k ^= k >> 31; // splitmix64 finaliser
+	return (u32)k & mask;
+}
+MI_DEV i32 cellCoord(float v, float invCell)
+{
+	float c = floorf(v * invCell);
+	c = fminf(fmaxf(c, -(float)(CELL_BIAS - 2)), (float)(CELL_BIAS - 2));
+	return (i32)c + CELL_BIAS;
+}
+MI_DEV bool aabbOverlap(float4 amin, float4 amax, float4 bmin, float4 bmax)
+{
+	if (amax.x < bmin.x || amin.x > bmax.x) return false;
+	if (amax.y < bmin.y || amin.y > bmax.y) return false;
+	if (amax.z < bmin.z || amin.z > bmax.z) return false;
+	return true;
+}
+
+// counters layout (u32 indices into World::dCounters) — mirrors StepCounters
+enum { CTR_NUM_PAIRS = 0, CTR_NUM_VALID = 1, CTR_NUM_MANIFOLDS = 2, CTR_NUM_CONTACTS = 3, CTR_NUM_COLORS = 4, CTR_NUM_LARGE = 5, CTR_ROUNDS_LEFT = 6, CTR_OVERFLOW = 7,
+	CTR_COLOR_START = 8, CTR_BUCKET_START = 8 + MI_MAX_COLORS + 2, CTR_CELL_SIZE = CTR_BUCKET_START + 32, CTR_FIRST_LARGE = CTR_CELL_SIZE + 1 };
+
+// Largest extent among colliders that ride on a rigid body.  max() is order-independent, so the atomic is deterministic.
+__global__ void __launch_bounds__(256) k_max_extent(u32 nc, u32 nb, const ColliderRec* __restrict__ colWorld, const float4* __restrict__ aabbMin,
+	const float4* __restrict__ aabbMax, u32* __restrict__ counters)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	float e = 0.f;
+	if (i < nc && colBody(colWorld[i]) < nb)
+	{
+		float4 mn = aabbMin[i], mx = aabbMax[i];
+		e = fmaxf(fmaxf(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+	}
+	for (int o = 32; o > 0; o >>= 1) e = fmaxf(e, __shfl_xor(e, o));
+	if ((threadIdx.x & 63) == 0 && e > 0.f) atomicMax(&counters[CTR_CELL_SIZE], __float_as_uint(e));
+}
+
+__global__ void __launch_bounds__(256) k_cell_assign(u32 nc, u32 hashMask, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+	const u32* __restrict__ counters, u32* __restrict__ hashKey, u32* __restrict__ sortIdx)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nc) return;
+	float maxExtent = fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f);
+	float cell = maxExtent * 1.001f;
+	float invCell = 1.f / cell;
+	float4 mn = aabbMin[i], mx = aabbMax[i];
+	float e = fmaxf(fmaxf(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+	u32 h;
+	if (e > maxExtent) { h = hashMask + 1; } // large: sorts behind every grid cell
+	else { h = hashCell(packCell(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell)), hashMask); }
+	hashKey[i] = h;
+	sortIdx[i] = i;
+}
+
+__global__ void __launch_bounds__(256) k_gather_sorted(u32 nc, u32 hashMask, const u32* __restrict__ hashSorted, const u32* __restrict__ idxSorted,
+	const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax, u32* __restrict__ counters,
+	u64* __restrict__ sCellKey, float4* __restrict__ sMin, float4* __restrict__ sMax, u32* __restrict__ cellStart, u32* __restrict__ cellEnd)
+{
+	u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nc) return;
+	u32 idx = idxSorted[t];
+	u32 h = hashSorted[t];
+	float cell = fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f) * 1.001f;
+	float invCell = 1.f / cell;
+	float4 mn = aabbMin[idx], mx = aabbMax[idx];
+	mn.w = __uint_as_float(idx);
+	sMin[t] = mn; sMax[t] = mx;
+	sCellKey[t] = packCell(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell));
+	u32 hPrev = (t > 0) ? hashSorted[t - 1] : 0xFFFFFFFFu;
+	u32 hNext = (t + 1 < nc) ? hashSorted[t + 1] : 0xFFFFFFFFu;
+	if (h <= hashMask)
+	{
+		if (hPrev != h) cellStart[h] = t;
+		if (hNext != h) cellEnd[h] = t + 1;
+	}
+	else if (hPrev != h) { counters[CTR_FIRST_LARGE] = t; }
+}
+
+// Count (WRITE=false) or emit (WRITE=true) the overlapping partners of the collider at sorted position t.
+// A pair is produced by the member with the larger sorted position, as (A = this collider, B = partner).
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* __restrict__ sCellKey, const float4* __restrict__ sMin, const float4* __restrict__ sMax,
+	const u32* __restrict__ cellStart, const u32* __restrict__ cellEnd, const u32* __restrict__ counters,
+	u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, uint2* __restrict__ pairs, u32 pairCap)
+{
+	u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nc) return;
+	u32 firstLarge = min(counters[CTR_FIRST_LARGE], nc);
+	float4 amin = sMin[t], amax = sMax[t];
+	u32 me = __float_as_uint(amin.w);
+	u32 n = 0;
+	u32 out = WRITE ? pairOffset[t] : 0;
+
+	if (t >= firstLarge)
+	{
+		for (u32 u = firstLarge; u < t; ++u)
+		{
+			float4 bmin = sMin[u], bmax = sMax[u];
+			if (aabbOverlap(amin, amax, bmin, bmax))
+			{
+				if (WRITE) { if (out + n < pairCap) pairs[out + n] = make_uint2(me, __float_as_uint(bmin.w)); }
+				++n;
+			}
+		}
+	}
+	else
+	{
+		u64 key = sCellKey[t];
+		i32 ix = (i32)(key & CELL_MASK), iy = (i32)((key >> 21) & CELL_MASK), iz = (i32)((key >> 42) & CELL_MASK);
+		for (i32 dz = -1; dz <= 1; ++dz)
+		for (i32 dy = -1; dy <= 1; ++dy)
+		for (i32 dx = -1; dx <= 1; ++dx)
+		{
+			u64 nkey = packCell(ix + dx, iy + dy, iz + dz);
+			u32 h = hashCell(nkey, hashMask);
+			u32 s = cellStart[h];
+			if (s == EMPTY_CELL) continue;
+			u32 e = min(cellEnd[h], t); // only partners sorted before me
+			for (u32 u = s; u < e; ++u)
+			{
+				if (sCellKey[u] != nkey) continue; // other cell sharing the hash bucket
+				float4 bmin = sMin[u], bmax = sMax[u];
+				if (aabbOverlap(amin, amax, bmin, bmax))
+				{
+					if (WRITE) { if (out + n < pairCap) pairs[out + n] = make_uint2(me, __float_as_uint(bmin.w)); }
+					++n;
+				}
+			}
+		}
+		for (u32 u = firstLarge; u < nc; ++u)
+		{
+			float4 bmin = sMin[u], bmax = sMax[u];
+			if (aabbOverlap(amin, amax, bmin, bmax))
+			{
+				if (WRITE) { if (out + n < pairCap) pairs[out + n] = make_uint2(me, __float_as_uint(bmin.w)); }
+				++n;
+			}
+		}
+	}
+	if (!WRITE) pairCount[t] = n;
+}
+
+__global__ void k_finish_pair_count(u32 nc, const u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, u32* __restrict__ counters)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) counters[CTR_NUM_PAIRS] = nc ? pairOffset[nc - 1] + pairCount[nc - 1] : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rocPRIM wrappers (radix sort / exclusive scan).  Temp storage grows on demand, outside the steady state.
+// ---------------------------------------------------------------------------------------------------------------
+static void ensureTemp(World& w, size_t bytes)
+{
+	if (bytes > w.tempStorage.cap) w.tempStorage.ensure(bytes + bytes / 2 + 4096, w.stream);
+}
+void prim_sort_pairs_u32(World& w, const u32* kin, u32* kout, const u32* vin, u32* vout, u32 n, u32 bits)
+{
+	if (!n) return;
+	size_t bytes = 0;
+	MI_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits, w.stream));
+	ensureTemp(w, bytes);
+	MI_CHECK(rocprim::radix_sort_pairs(w.tempStorage.p, bytes, kin, kout, vin, vout, n, 0, bits, w.stream));
+}
+void prim_sort_pairs_u32_u64(World& w, const u32* kin, u32* kout, const u64* vin, u64* vout, u32 n, u32 bits)
+{
+	if (!n) return;
+	size_t bytes = 0;
+	MI_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0, bits, w.stream));
+	ensureTemp(w, bytes);
+	MI_CHECK(rocprim::radix_sort_pairs(w.tempStorage.p, bytes, kin, kout, vin, vout, n, 0, bits, w.stream));
+}
+void prim_exclusive_scan_u32(World& w, const u32* in, u32* out, u32 n)
+{
+	if (!n) return;
+	size_t bytes = 0;
+	MI_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, 0u, n, rocprim::plus<u32>(), w.stream));
+	ensureTemp(w, bytes);
+	MI_CHECK(rocprim::exclusive_scan(w.tempStorage.p, bytes, in, out, 0u, n, rocprim::plus<u32>(), w.stream));
+}
+
+static u32 log2ceil(u32 v) { u32 b = 0; while ((1u << b) < v) ++b; return b; }
+
+void launch_broadphase_count(World& w)
+{
+	u32 nc = w.nc;
+	if (!nc) return;
+	dim3 grid((nc + 255) / 256), block(256);
+	u32 H = w.hashTableSize, mask = H - 1;
+	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CELL_SIZE, 0, sizeof(u32), w.stream));
+	MI_CHECK(hipMemsetAsync(w.cellStart.p, 0xFF, sizeof(u32) * H, w.stream));
+	hipLaunchKernelGGL(k_max_extent, grid, block, 0, w.stream, nc, w.nb, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p);
+	hipLaunchKernelGGL(k_cell_assign, grid, block, 0, w.stream, nc, mask, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.hashKey.p, w.sortIdx.p);
+	prim_sort_pairs_u32(w, w.hashKey.p, w.hashKeySorted.p, w.sortIdx.p, w.sortIdxSorted.p, nc, log2ceil(H) + 1);
+	u32 ncAsFirstLarge = nc;
+	MI_CHECK(hipMemcpyAsync(w.dCounters.p + CTR_FIRST_LARGE, &ncAsFirstLarge, sizeof(u32), hipMemcpyHostToDevice, w.stream));
+	hipLaunchKernelGGL(k_gather_sorted, grid, block, 0, w.stream, nc, mask, w.hashKeySorted.p, w.sortIdxSorted.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p,
+		w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<false>), grid, block, 0, w.stream, nc, mask, w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p, w.dCounters.p,
+		w.pairCount.p, w.pairOffset.p, w.pairs.p, 0u);
+	prim_exclusive_scan_u32(w, w.pairCount.p, w.pairOffset.p, nc);
+	hipLaunchKernelGGL(k_finish_pair_count, dim3(1), dim3(64), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.dCounters.p);
+}
+
+void launch_broadphase_write(World& w, u32 numPairs)
+{
+	u32 nc = w.nc;
+	if (!nc || !numPairs) return;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<true>), dim3((nc + 255) / 256), dim3(256), 0, w.stream, nc, w.hashTableSize - 1, w.sCellKey.p, w.sMin.p, w.sMax.p,
+		w.cellStart.p, w.cellEnd.p, w.dCounters.p, w.pairCount.p, w.pairOffset.p, w.pairs.p, (u32)w.pairCap);
+}

@@ -1,0 +1,838 @@
+// Narrowphase: prune / classify / bucket (reference collision_narrow.cpp:2346-2453), then one branch-uniform kernel family per
+// group of type pairs: closed forms (:374-612, :1074-1140), box-box SAT + Sutherland-Hodgman clipping (:1179-1527) and
+// GJK + EPA for capsule vs box (:705-790, collision_gjk.{h,cpp}, collision_epa.{h,cpp}).  One thread per candidate pair; every
+// pair writes a 96-byte ManifoldRec (count 0 = no collision) so contact generation needs no atomics and keeps pair order.
+// Hull pairs and cylinder pairs are not built (SURVEY §8 a19 / out of the BASELINE configs).
+#include "world.h"
+#include <rocprim/rocprim.hpp>
+
+void prim_sort_pairs_u32_u64(World& w, const u32* kin, u32* kout, const u64* vin, u64* vout, u32 n, u32 bits);
+
+enum { CTR_NUM_PAIRS = 0, CTR_NUM_VALID = 1, CTR_BUCKET_START = 8 + MI_MAX_COLORS + 2 };
+#define KEY_INVALID 63u
+
+struct Man { V3 n; float4 p[4]; u32 count; };
+
+MI_DEV bool typeSupported(u32 t) { return t == MI_SPHERE || t == MI_CAPSULE || t == MI_AABB || t == MI_OBB; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// K5: prune + classify.  Reads the 16-B tag quarter of both colliders.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_classify(const u32* __restrict__ counters, u32 nb, const uint2* __restrict__ pairs, const ColliderRec* __restrict__ colWorld,
+	u32* __restrict__ pairKey, u64* __restrict__ pairPacked)
+{
+	u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= counters[CTR_NUM_PAIRS]) return;
+	uint2 pr = pairs[p];
+	float4 da = colWorld[pr.x].d, db = colWorld[pr.y].d;
+	u32 tA = __float_as_uint(da.x), tB = __float_as_uint(db.x), bA = __float_as_uint(da.y), bB = __float_as_uint(db.y);
+	u32 key = KEY_INVALID;
+	bool rbA = bA < nb, rbB = bB < nb;
+	if ((rbA || rbB) && !(rbA && rbB && bA == bB) && typeSupported(tA) && typeSupported(tB)) // :2358-2369
+	{
+		if (!(tA < tB)) { u32 t = pr.x; pr.x = pr.y; pr.y = t; t = tA; tA = tB; tB = t; } // :2374 — swaps on equal types too
+		key = tA * 6 + tB;
+	}
+	pairKey[p] = key;
+	pairPacked[p] = ((u64)pr.y << 32) | pr.x;
+}
+
+__global__ void k_bucket_offsets(u32* __restrict__ counters, const u32* __restrict__ keySorted)
+{
+	u32 b = threadIdx.x; // bucket key 0..63
+	u32 n = counters[CTR_NUM_PAIRS];
+	u32 lo = 0, hi = n;
+	while (lo < hi) { u32 mid = (lo + hi) >> 1; if (keySorted[mid] < b) lo = mid + 1; else hi = mid; }
+	if (b < 32) counters[CTR_BUCKET_START + b] = lo; // keys >= 32 never occur below KEY_INVALID (max valid = 4*6+4 = 28)
+	if (b == KEY_INVALID) counters[CTR_NUM_VALID] = lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Shape accessors
+// ---------------------------------------------------------------------------------------------------------------
+struct Sphere { V3 c; float r; };
+struct Capsule { V3 a, b; float r; };
+struct Box { V3 lo, hi; };
+struct Obb { Q4 q; V3 c, r; };
+MI_DEV Sphere asSphere(const ColliderRec& c) { Sphere s; s.c = v3(c.a.x, c.a.y, c.a.z); s.r = c.a.w; return s; }
+MI_DEV Capsule asCapsule(const ColliderRec& c) { Capsule s; s.a = v3(c.a.x, c.a.y, c.a.z); s.b = v3(c.a.w, c.b.x, c.b.y); s.r = c.b.z; return s; }
+MI_DEV Box asBox(const ColliderRec& c) { Box s; s.lo = v3(c.a.x, c.a.y, c.a.z); s.hi = v3(c.a.w, c.b.x, c.b.y); return s; }
+MI_DEV Obb asObb(const ColliderRec& c) { Obb s; s.q = q4f4(c.a); s.c = v3(c.b.x, c.b.y, c.b.z); s.r = v3(c.b.w, c.c.x, c.c.y); return s; }
+MI_DEV V3 boxCenter(const Box& b) { return (b.lo + b.hi) * 0.5f; }
+MI_DEV V3 boxRadius(const Box& b) { return (b.hi - b.lo) * 0.5f; }
+
+MI_DEV V3 closestPointSegment(V3 q, V3 a, V3 b) // bounding_volumes.h:365-371
+{
+	V3 ab = b - a;
+	float t = dot(q - a, ab) / sqlen(ab);
+	t = clampf(t, 0.f, 1.f);
+	return a + t * ab;
+}
+MI_DEV float closestSegmentSegment(V3 l1a, V3 l1b, V3 l2a, V3 l2b, V3& c1, V3& c2) // bounding_volumes.cpp:1251-1315
+{
+	float s, t;
+	V3 d1 = l1b - l1a, d2 = l2b - l2a, r = l1a - l2a;
+	float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+	if (a <= MI_EPSILON && e <= MI_EPSILON) { c1 = l1a; c2 = l2a; return dot(c1 - c2, c1 - c2); }
+	if (a <= MI_EPSILON) { s = 0.f; t = f / e; t = clampf(t, 0.f, 1.f); }
+	else
+	{
+		float c = dot(d1, r);
+		if (e <= MI_EPSILON) { t = 0.f; s = clampf(-c / a, 0.f, 1.f); }
+		else
+		{
+			float b = dot(d1, d2);
+			float denom = a * e - b * b;
+			if (denom != 0.f) s = clampf((b * f - c * e) / denom, 0.f, 1.f); else s = 0.f;
+			t = (b * s + f) / e;
+			if (t < 0.f) { t = 0.f; s = clampf(-c / a, 0.f, 1.f); }
+			else if (t > 1.f) { t = 1.f; s = clampf((b - c) / a, 0.f, 1.f); }
+		}
+	}
+	c1 = l1a + d1 * s;
+	c2 = l2a + d2 * t;
+	return sqlen(c1 - c2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Closed-form pair kernels
+// ---------------------------------------------------------------------------------------------------------------
+MI_DEV bool sphereSphere(Sphere s1, Sphere s2, Man& m) // collision_narrow.cpp:374-400
+{
+	V3 n = s2.c - s1.c;
+	float radiusSum = s2.r + s1.r;
+	float sq = sqlen(n);
+	if (sq <= radiusSum * radiusSum)
+	{
+		float distance;
+		if (sq == 0.f) { distance = 0.f; m.n = v3(0.f, 1.f, 0.f); }
+		else { distance = sqrtf(sq); m.n = n / distance; }
+		m.count = 1;
+		V3 pt = 0.5f * (s1.c + s1.r * m.n + s2.c - s2.r * m.n);
+		m.p[0] = make_float4(pt.x, pt.y, pt.z, radiusSum - distance);
+		return true;
+	}
+	return false;
+}
+MI_DEV bool sphereCapsule(Sphere s, Capsule c, Man& m) // :402-406
+{
+	Sphere s2; s2.c = closestPointSegment(s.c, c.a, c.b); s2.r = c.r;
+	return sphereSphere(s, s2, m);
+}
+MI_DEV bool sphereBox(Sphere s, Box a, Man& m) // :451-478
+{
+	V3 p = v3(fminf(fmaxf(s.c.x, a.lo.x), a.hi.x), fminf(fmaxf(s.c.y, a.lo.y), a.hi.y), fminf(fmaxf(s.c.z, a.lo.z), a.hi.z)); // closestPoint_PointAABB
+	V3 n = p - s.c;
+	float sq = sqlen(n);
+	if (sq <= s.r * s.r)
+	{
+		float dist = 0.f;
+		if (sq > 0.f) { dist = sqrtf(sq); n = n / dist; }
+		else { n = v3(0.f, 1.f, 0.f); }
+		m.count = 1;
+		m.n = n;
+		V3 pt = 0.5f * (p + s.c + n * s.r);
+		m.p[0] = make_float4(pt.x, pt.y, pt.z, s.r - dist);
+		return true;
+	}
+	return false;
+}
+MI_DEV bool sphereObb(Sphere s, Obb o, Man& m) // :480-494
+{
+	Box aabb; aabb.lo = o.c - o.r; aabb.hi = o.c + o.r;
+	Sphere s_; s_.c = conjugate(o.q) * (s.c - o.c) + o.c; s_.r = s.r;
+	if (sphereBox(s_, aabb, m))
+	{
+		m.n = o.q * m.n;
+		V3 pt = o.q * (v3f4(m.p[0]) - o.c) + o.c;
+		m.p[0] = make_float4(pt.x, pt.y, pt.z, m.p[0].w);
+		return true;
+	}
+	return false;
+}
+MI_DEV bool capsuleCapsule(Capsule a, Capsule b, Man& m) // :523-612
+{
+	V3 aDir = a.b - a.a;
+	V3 bDir = normalize(b.b - b.a);
+	float aDirLength = length(aDir);
+	aDir *= 1.f / aDirLength;
+	float parallel = dot(aDir, bDir);
+	if (fabsf(parallel) > 0.99f)
+	{
+		V3 pAa = a.a, pAb = a.b, pBa = b.a, pBb = b.b;
+		if (parallel < 0.f) { V3 t = pBa; pBa = pBb; pBb = t; }
+		V3 ref = a.a;
+		float a0 = 0.f, a1 = aDirLength;
+		float b0 = dot(aDir, pBa - ref), b1 = dot(aDir, pBb - ref);
+		float left = fmaxf(a0, b0), right = fminf(a1, b1);
+		if (right < left)
+		{
+			Sphere sa, sb; sa.r = a.r; sb.r = b.r;
+			if (a0 > b1) { sa.c = pAa; sb.c = pBb; } else { sa.c = pAb; sb.c = pBa; }
+			return sphereSphere(sa, sb, m);
+		}
+		V3 contactA0 = ref + left * aDir, contactA1 = ref + right * aDir;
+		V3 contactB0 = closestPointSegment(contactA0, pBa, pBb);
+		V3 contactB1 = contactB0 + (right - left) * aDir;
+		V3 normal = contactB0 - contactA0;
+		float d = length(normal);
+		if (d < MI_EPSILON) { d = 0.f; normal = v3(0.f, 1.f, 0.f); } else { normal = normal / d; }
+		float penetration = (a.r + b.r) - d;
+		if (penetration < 0.f) return false;
+		m.n = normal; m.count = 2;
+		V3 p0 = (contactA0 + contactB0) * 0.5f, p1 = (contactA1 + contactB1) * 0.5f;
+		m.p[0] = make_float4(p0.x, p0.y, p0.z, penetration);
+		m.p[1] = make_float4(p1.x, p1.y, p1.z, penetration);
+		return true;
+	}
+	V3 c1, c2;
+	closestSegmentSegment(a.a, a.b, b.a, b.b, c1, c2);
+	Sphere sa, sb; sa.c = c1; sa.r = a.r; sb.c = c2; sb.r = b.r;
+	return sphereSphere(sa, sb, m);
+}
+MI_DEV bool boxBoxAxisAligned(Box a, Box b, Man& m) // :1074-1140
+{
+	V3 centerA = boxCenter(a), centerB = boxCenter(b), radiusA = boxRadius(a), radiusB = boxRadius(b);
+	V3 d = centerB - centerA;
+	V3 p = (radiusB + radiusA) - vabs(d);
+	if (p.x < 0.f || p.y < 0.f || p.z < 0.f) return false;
+	u32 minElement = (p.x < p.y) ? ((p.x < p.z) ? 0 : 2) : ((p.y < p.z) ? 1 : 2);
+	float s = vget(d, minElement) < 0.f ? -1.f : 1.f;
+	float penetration = vget(p, minElement) * s;
+	V3 normal = v3s(0.f); vset(normal, minElement, s);
+	m.n = normal; m.count = 4;
+	u32 axis0 = (minElement + 1) % 3, axis1 = (minElement + 2) % 3;
+	float min0 = fmaxf(vget(a.lo, axis0), vget(b.lo, axis0)), min1 = fmaxf(vget(a.lo, axis1), vget(b.lo, axis1));
+	float max0 = fminf(vget(a.hi, axis0), vget(b.hi, axis0)), max1 = fminf(vget(a.hi, axis1), vget(b.hi, axis1));
+	float depth = vget(centerA, minElement) + vget(radiusA, minElement) - penetration * 0.5f;
+	for (u32 i = 0; i < 4; ++i)
+	{
+		V3 pt = v3s(0.f);
+		vset(pt, axis0, (i < 2) ? min0 : max0);
+		vset(pt, axis1, (i & 1) ? max1 : min1);
+		vset(pt, minElement, depth);
+		m.p[i] = make_float4(pt.x, pt.y, pt.z, penetration);
+	}
+	return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Manifold helpers — collision_narrow.cpp:56-369.  Polygon vertices are float4 (xyz, penetrationDepth).
+// ---------------------------------------------------------------------------------------------------------------
+struct Poly { float4 pts[16]; u32 n; };
+
+MI_DEV float4 clipAgainstPlane(float4 a, float4 b, float aDist, float bDist) // :154-163
+{
+	aDist = fabsf(aDist); bDist = fabsf(bDist);
+	float t = aDist / (aDist + bDist);
+	return make_float4(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z), a.w + t * (b.w - a.w));
+}
+MI_DEV void sutherlandHodgman(Poly& input, const float4* clipPlanes, u32 numClipPlanes, Poly& output) // :166-222
+{
+	Poly* in = &input; Poly* out = &output;
+	u32 clipIndex = 0;
+	for (; clipIndex < numClipPlanes; ++clipIndex)
+	{
+		float4 plane = clipPlanes[clipIndex];
+		out->n = 0;
+		if (in->n == 0) break;
+		float4 startPoint = in->pts[in->n - 1];
+		for (u32 i = 0; i < in->n; ++i)
+		{
+			float4 endPoint = in->pts[i];
+			float startDist = signedDistanceToPlane(v3f4(startPoint), plane);
+			float endDist = signedDistanceToPlane(v3f4(endPoint), plane);
+			bool startInside = startDist > 0.f, endInside = endDist > 0.f;
+			if (startInside && endInside) { out->pts[out->n++] = endPoint; }
+			else if (startInside) { out->pts[out->n++] = clipAgainstPlane(startPoint, endPoint, startDist, endDist); }
+			else if (!startInside && endInside)
+			{
+				out->pts[out->n++] = clipAgainstPlane(startPoint, endPoint, startDist, endDist);
+				out->pts[out->n++] = endPoint;
+			}
+			startPoint = endPoint;
+		}
+		Poly* tmp = in; in = out; out = tmp;
+	}
+	if (clipIndex % 2 == 0)
+	{
+		for (u32 i = 0; i < input.n; ++i) output.pts[i] = input.pts[i];
+		output.n = input.n;
+	}
+}
+MI_DEV void findStableContactManifold(const float4* v, u32 nv, V3 normal, Man& m) // :56-146
+{
+	if (nv > 4)
+	{
+		V3 searchDir = getTangent(normal);
+		float best = dot(searchDir, v3f4(v[0]));
+		u32 ri = 0;
+		for (u32 i = 1; i < nv; ++i) { float d = dot(searchDir, v3f4(v[i])); if (d > best) { ri = i; best = d; } }
+		m.p[0] = v[ri];
+		best = 0.f; ri = 0;
+		for (u32 i = 0; i < nv; ++i) { float d = sqlen(v3f4(v[i]) - v3f4(m.p[0])); if (d > best) { ri = i; best = d; } }
+		m.p[1] = v[ri];
+		best = 0.f; ri = 0;
+		for (u32 i = 0; i < nv; ++i)
+		{
+			V3 qa = v3f4(m.p[0]) - v3f4(v[i]), qb = v3f4(m.p[1]) - v3f4(v[i]);
+			float area = 0.5f * dot(cross(qa, qb), normal);
+			if (area > best) { ri = i; best = area; }
+		}
+		m.p[2] = v[ri];
+		best = 0.f; ri = 0;
+		for (u32 i = 0; i < nv; ++i)
+		{
+			V3 qa = v3f4(m.p[0]) - v3f4(v[i]), qb = v3f4(m.p[1]) - v3f4(v[i]), qc = v3f4(m.p[2]) - v3f4(v[i]);
+			float area1 = 0.5f * dot(cross(qa, qb), normal);
+			float area2 = 0.5f * dot(cross(qb, qc), normal);
+			float area3 = 0.5f * dot(cross(qc, qa), normal);
+			float area = fmaxf(fmaxf(area1, area2), area3);
+			if (area > best) { ri = i; best = area; }
+		}
+		m.p[3] = v[ri];
+		m.count = 4;
+	}
+	else
+	{
+		m.count = nv;
+		for (u32 i = 0; i < nv; ++i) m.p[i] = v[i];
+	}
+}
+MI_DEV bool clipPointsAndBuildContact(Poly& polygon, const float4* clipPlanes, float4 referencePlane, Man& m) // :339-369
+{
+	Poly clipped; clipped.n = 0;
+	sutherlandHodgman(polygon, clipPlanes, 4, clipped);
+	if (clipped.n > 0)
+	{
+		for (u32 i = 0; i < clipped.n; ++i)
+		{
+			if (clipped.pts[i].w < 0.f)
+			{
+				clipped.pts[i] = clipped.pts[clipped.n - 1];
+				--clipped.n;
+				--i;
+			}
+			else
+			{
+				float d = clipped.pts[i].w;
+				clipped.pts[i].x += referencePlane.x * d; clipped.pts[i].y += referencePlane.y * d; clipped.pts[i].z += referencePlane.z * d;
+			}
+		}
+		if (clipped.n > 0) { findStableContactManifold(clipped.pts, clipped.n, m.n, m); return true; }
+	}
+	return false;
+}
+MI_DEV void getAABBClippingPlanes(V3 radius, V3 normal, V3* pts, V3* nrm) // :225-254
+{
+	V3 p = vabs(normal);
+	u32 maxElement = (p.x > p.y) ? ((p.x > p.z) ? 0 : 2) : ((p.y > p.z) ? 1 : 2);
+	u32 axis0 = (maxElement + 1) % 3, axis1 = (maxElement + 2) % 3;
+	V3 n;
+	n = v3s(0.f); vset(n, axis0, 1.f); nrm[0] = n; pts[0] = -radius;
+	n = v3s(0.f); vset(n, axis1, 1.f); nrm[1] = n; pts[1] = -radius;
+	n = v3s(0.f); vset(n, axis0, -1.f); nrm[2] = n; pts[2] = radius;
+	n = v3s(0.f); vset(n, axis1, -1.f); nrm[3] = n; pts[3] = radius;
+}
+MI_DEV void getAABBIncidentVertices(V3 radius, V3 normal, V3* verts) // :257-289
+{
+	V3 p = vabs(normal);
+	u32 maxElement = (p.x > p.y) ? ((p.x > p.z) ? 0 : 2) : ((p.y > p.z) ? 1 : 2);
+	float s = vget(normal, maxElement) < 0.f ? 1.f : -1.f;
+	u32 axis0 = (maxElement + 1) % 3, axis1 = (maxElement + 2) % 3;
+	float d = vget(radius, maxElement) * s;
+	float min0 = -vget(radius, axis0), min1 = -vget(radius, axis1), max0 = vget(radius, axis0), max1 = vget(radius, axis1);
+	for (u32 i = 0; i < 4; ++i)
+	{
+		V3 v = v3s(0.f);
+		vset(v, maxElement, d);
+		vset(v, axis0, (i == 1 || i == 2) ? max0 : min0);
+		vset(v, axis1, (i >= 2) ? max1 : min1);
+		verts[i] = v;
+	}
+}
+MI_DEV void getAABBIncidentEdge(V3 radius, V3 normal, V3& outA, V3& outB) // :301-336
+{
+	V3 p = vabs(normal);
+	outA = radius;
+	if (p.x > p.y) { if (p.y > p.z) outB = v3(radius.x, radius.y, -radius.z); else outB = v3(radius.x, -radius.y, radius.z); }
+	else { if (p.x > p.z) outB = v3(radius.x, radius.y, -radius.z); else outB = v3(-radius.x, radius.y, radius.z); }
+	V3 sgn = v3(normal.x < 0.f ? -1.f : 1.f, normal.y < 0.f ? -1.f : 1.f, normal.z < 0.f ? -1.f : 1.f);
+	outA = outA * sgn; outB = outB * sgn;
+}
+MI_DEV V3 obbSupport(const Obb& b, V3 dir) // collision_gjk.h:63-75
+{
+	dir = conjugate(b.q) * dir;
+	V3 r = v3(dir.x < 0.f ? -b.r.x : b.r.x, dir.y < 0.f ? -b.r.y : b.r.y, dir.z < 0.f ? -b.r.z : b.r.z);
+	return b.c + b.q * r;
+}
+
+// OBB vs OBB — collision_narrow.cpp:1179-1527
+MI_DEV bool obbObb(const Obb& a, const Obb& b, Man& m)
+{
+	V3 ax = a.q * v3(1.f, 0.f, 0.f), ay = a.q * v3(0.f, 1.f, 0.f), az = a.q * v3(0.f, 0.f, 1.f);
+	V3 bx = b.q * v3(1.f, 0.f, 0.f), by = b.q * v3(0.f, 1.f, 0.f), bz = b.q * v3(0.f, 0.f, 1.f);
+	M3 r;
+	r.m00 = dot(ax, bx); r.m10 = dot(ay, bx); r.m20 = dot(az, bx);
+	r.m01 = dot(ax, by); r.m11 = dot(ay, by); r.m21 = dot(az, by);
+	r.m02 = dot(ax, bz); r.m12 = dot(ay, bz); r.m22 = dot(az, bz);
+	V3 tw = b.c - a.c;
+	V3 t = conjugate(a.q) * tw;
+	M3 absR;
+	absR.m00 = fabsf(r.m00) + MI_EPSILON; absR.m10 = fabsf(r.m10) + MI_EPSILON; absR.m20 = fabsf(r.m20) + MI_EPSILON;
+	absR.m01 = fabsf(r.m01) + MI_EPSILON; absR.m11 = fabsf(r.m11) + MI_EPSILON; absR.m21 = fabsf(r.m21) + MI_EPSILON;
+	absR.m02 = fabsf(r.m02) + MI_EPSILON; absR.m12 = fabsf(r.m12) + MI_EPSILON; absR.m22 = fabsf(r.m22) + MI_EPSILON;
+	bool parallel = absR.m00 >= 0.99f || absR.m10 >= 0.99f || absR.m20 >= 0.99f || absR.m01 >= 0.99f || absR.m11 >= 0.99f || absR.m21 >= 0.99f
+		|| absR.m02 >= 0.99f || absR.m12 >= 0.99f || absR.m22 >= 0.99f;
+
+	float ra, rb;
+	float minPenetration = MI_FLT_MAX;
+	V3 normal = v3s(0.f);
+	bool bFace = false;
+	for (u32 i = 0; i < 3; ++i)
+	{
+		ra = vget(a.r, i);
+		rb = dot(mrow(absR, i), b.r);
+		float penetration = ra + rb - fabsf(vget(t, i));
+		if (penetration < 0.f) return false;
+		if (penetration < minPenetration) { minPenetration = penetration; normal = v3s(0.f); vset(normal, i, 1.f); }
+	}
+	for (u32 i = 0; i < 3; ++i)
+	{
+		ra = dot(mcol(absR, i), a.r);
+		rb = vget(b.r, i);
+		float d = dot(mcol(r, i), t);
+		float penetration = ra + rb - fabsf(d);
+		if (penetration < 0.f) return false;
+		if (penetration < minPenetration) { minPenetration = penetration; normal = v3s(0.f); vset(normal, i, 1.f); bFace = true; }
+	}
+	bool edgeCollision = false;
+	V3 edgeNormal = v3s(0.f);
+	if (!parallel)
+	{
+		float penetration, l; V3 n;
+#define MI_EDGE_TEST(RA, RB, DIST, NX, NY, NZ) \
+		ra = RA; rb = RB; penetration = ra + rb - fabsf(DIST); \
+		if (penetration < 0.f) return false; \
+		n = v3(NX, NY, NZ); l = 1.f / length(n); penetration *= l; \
+		if (penetration < minPenetration) { minPenetration = penetration; edgeNormal = n * l; edgeCollision = true; }
+		MI_EDGE_TEST(a.r.y * absR.m20 + a.r.z * absR.m10, b.r.y * absR.m02 + b.r.z * absR.m01, t.z * r.m10 - t.y * r.m20, 0.f, -r.m20, r.m10)
+		MI_EDGE_TEST(a.r.y * absR.m21 + a.r.z * absR.m11, b.r.x * absR.m02 + b.r.z * absR.m00, t.z * r.m11 - t.y * r.m21, 0.f, -r.m21, r.m11)
+		MI_EDGE_TEST(a.r.y * absR.m22 + a.r.z * absR.m12, b.r.x * absR.m01 + b.r.y * absR.m00, t.z * r.m12 - t.y * r.m22, 0.f, -r.m22, r.m12)
+		MI_EDGE_TEST(a.r.x * absR.m20 + a.r.z * absR.m00, b.r.y * absR.m12 + b.r.z * absR.m11, t.x * r.m20 - t.z * r.m00, r.m20, 0.f, -r.m00)
+		MI_EDGE_TEST(a.r.x * absR.m21 + a.r.z * absR.m01, b.r.x * absR.m12 + b.r.z * absR.m10, t.x * r.m21 - t.z * r.m01, r.m21, 0.f, -r.m01)
+		MI_EDGE_TEST(a.r.x * absR.m22 + a.r.z * absR.m02, b.r.x * absR.m11 + b.r.y * absR.m10, t.x * r.m22 - t.z * r.m02, r.m22, 0.f, -r.m02)
+		MI_EDGE_TEST(a.r.x * absR.m10 + a.r.y * absR.m00, b.r.y * absR.m22 + b.r.z * absR.m21, t.y * r.m00 - t.x * r.m10, -r.m10, r.m00, 0.f)
+		MI_EDGE_TEST(a.r.x * absR.m11 + a.r.y * absR.m01, b.r.x * absR.m22 + b.r.z * absR.m20, t.y * r.m01 - t.x * r.m11, -r.m11, r.m01, 0.f)
+		MI_EDGE_TEST(a.r.x * absR.m12 + a.r.y * absR.m02, b.r.x * absR.m21 + b.r.y * absR.m20, t.y * r.m02 - t.x * r.m12, -r.m12, r.m02, 0.f)
+#undef MI_EDGE_TEST
+	}
+	bool faceCollision = !edgeCollision;
+	if (faceCollision) { if (bFace) normal = r * normal; }
+	else normal = edgeNormal;
+	normal = a.q * normal;
+	if (dot(normal, tw) < 0.f) normal = -normal;
+	m.n = normal;
+
+	if (faceCollision)
+	{
+		V3 cpp[4], cpn[4], verts[4];
+		Poly polygon; polygon.n = 4;
+		float4 plane;
+		if (!bFace)
+		{
+			getAABBClippingPlanes(a.r, conjugate(a.q) * normal, cpp, cpn);
+			getAABBIncidentVertices(b.r, conjugate(b.q) * normal, verts);
+			for (u32 i = 0; i < 4; ++i) { cpp[i] = a.q * cpp[i] + a.c; cpn[i] = a.q * cpn[i]; verts[i] = b.q * verts[i] + b.c; }
+			plane = createPlane(obbSupport(a, normal), normal);
+		}
+		else
+		{
+			getAABBClippingPlanes(b.r, conjugate(b.q) * -normal, cpp, cpn);
+			getAABBIncidentVertices(a.r, conjugate(a.q) * -normal, verts);
+			for (u32 i = 0; i < 4; ++i) { cpp[i] = b.q * cpp[i] + b.c; cpn[i] = b.q * cpn[i]; verts[i] = a.q * verts[i] + a.c; }
+			plane = createPlane(obbSupport(b, -normal), -normal);
+		}
+		float4 clipPlanes[4];
+		for (u32 i = 0; i < 4; ++i)
+		{
+			clipPlanes[i] = createPlane(cpp[i], cpn[i]);
+			polygon.pts[i] = make_float4(verts[i].x, verts[i].y, verts[i].z, -signedDistanceToPlane(verts[i], plane));
+		}
+		if (!clipPointsAndBuildContact(polygon, clipPlanes, plane, m)) return false;
+	}
+	else
+	{
+		V3 a0, a1, b0, b1;
+		getAABBIncidentEdge(a.r, conjugate(a.q) * normal, a0, a1);
+		getAABBIncidentEdge(b.r, conjugate(b.q) * -normal, b0, b1);
+		a0 = a.q * a0 + a.c; a1 = a.q * a1 + a.c; b0 = b.q * b0 + b.c; b1 = b.q * b1 + b.c;
+		V3 pa, pb;
+		float sq = closestSegmentSegment(a0, a1, b0, b1, pa, pb);
+		V3 pt = (pa + pb) * 0.5f;
+		m.count = 1;
+		m.p[0] = make_float4(pt.x, pt.y, pt.z, sqrtf(sq));
+	}
+	return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GJK + EPA for capsule vs axis-aligned box — collision_gjk.h:17-28,48-61,140-238; collision_gjk.cpp:6-212;
+// collision_epa.h:96-168; collision_epa.cpp:5-239.  Array sizes: the reference's 1024-entry arrays can hold at most
+// 24 points after its 20 iterations; triangles/edges are sized from measured high-water marks (46 / 48 on the test scenes)
+// with 2x headroom, and the reference's out-of-memory exits are kept.
+// ---------------------------------------------------------------------------------------------------------------
+#define EPA_MAX_POINTS 24
+#define EPA_MAX_TRIANGLES 96
+#define EPA_MAX_EDGES 128
+#define EPA_MAX_BORDER 32
+#define GJK_MAX_ITERATIONS 64
+
+struct SupportPoint { V3 a, b, mk; };
+struct GjkSimplex { SupportPoint a, b, c, d; u32 numPoints; };
+
+MI_DEV V3 capsuleSupport(const Capsule& c, V3 dir)
+{
+	float distA = dot(dir, c.a), distB = dot(dir, c.b);
+	V3 farther = distA > distB ? c.a : c.b;
+	return normalize(dir) * c.r + farther;
+}
+MI_DEV V3 boxSupport(const Box& b, V3 dir) { return v3((dir.x < 0.f) ? b.lo.x : b.hi.x, (dir.y < 0.f) ? b.lo.y : b.hi.y, (dir.z < 0.f) ? b.lo.z : b.hi.z); }
+MI_DEV SupportPoint supportCB(const Capsule& c, const Box& b, V3 dir)
+{
+	SupportPoint s; s.a = capsuleSupport(c, dir); s.b = boxSupport(b, -dir); s.mk = s.a - s.b; return s;
+}
+MI_DEV V3 crossABA(V3 a, V3 b) { return cross(cross(a, b), a); }
+
+// returns 0 = stop, 1 = continue, 2 = error
+MI_DEV int updateGJKSimplex(GjkSimplex& s, const SupportPoint& a, V3& dir)
+{
+	if (s.numPoints == 2)
+	{
+		V3 ao = -a.mk, ab = s.b.mk - a.mk, ac = s.c.mk - a.mk;
+		V3 abc = cross(ab, ac);
+		V3 abp = cross(ab, abc);
+		if (dot(ao, abp) > 0.f) { s.c = a; dir = crossABA(ab, ao); return 1; }
+		V3 acp = cross(abc, ac);
+		if (dot(ao, acp) > 0.f) { s.b = a; dir = crossABA(ac, ao); return 1; }
+		if (dot(ao, abc) >= 0.f) { s.d = s.b; s.b = a; s.numPoints = 3; dir = abc; return 1; }
+		if (dot(ao, -abc) >= 0.f) { s.d = s.c; s.c = s.b; s.b = a; s.numPoints = 3; dir = -abc; return 1; }
+		return 2;
+	}
+	if (s.numPoints == 3)
+	{
+		V3 ao = -a.mk, ab = s.b.mk - a.mk, ac = s.c.mk - a.mk, ad = s.d.mk - a.mk;
+		V3 bcd = cross(s.c.mk - s.b.mk, s.d.mk - s.b.mk);
+		if (dot(bcd, dir) > 0.00001f || dot(bcd, s.b.mk) < -0.00001f) return 2;
+		V3 abc = cross(ac, ab), abd = cross(ab, ad), adc = cross(ad, ac);
+		const int ABC = 1, ABD = 2, ADC = 4;
+		int flags = 0;
+		flags |= (dot(abc, ao) > 0.f) ? ABC : 0;
+		flags |= (dot(abd, ao) > 0.f) ? ABD : 0;
+		flags |= (dot(adc, ao) > 0.f) ? ADC : 0;
+		if (flags == (ABC | ABD | ADC)) return 2;
+		if (flags == 0) return 0;
+		// The reference's goto web (collision_gjk.cpp:95-205) as a small state machine: entry = (face, first|second test).
+		int face, second = 0;
+		if (flags == ABC) { face = ABC; }
+		else if (flags == ABD) { face = ABD; }
+		else if (flags == ADC) { face = ADC; }
+		else if (flags == (ABC | ABD)) { if (dot(cross(abc, ab), ao) > 0.f) { face = ABD; } else { face = ABC; second = 1; } }
+		else if (flags == (ABD | ADC)) { if (dot(cross(abd, ad), ao) > 0.f) { face = ADC; } else { face = ABD; second = 1; } }
+		else { if (dot(cross(adc, ac), ao) > 0.f) { face = ABC; } else { face = ADC; second = 1; } }
+		if (face == ABC)
+		{
+			if (!second && dot(cross(abc, ab), ao) > 0.f) { s.c = a; s.numPoints = 2; dir = crossABA(ab, ao); return 1; }
+			if (dot(cross(ac, abc), ao) > 0.f) { s.b = a; s.numPoints = 2; dir = crossABA(ac, ao); return 1; }
+			s.d = a; dir = abc; return 1;
+		}
+		if (face == ABD)
+		{
+			if (!second && dot(cross(abd, ad), ao) > 0.f) { s.b = s.d; s.c = a; s.numPoints = 2; dir = crossABA(ad, ao); return 1; }
+			if (dot(cross(ab, abd), ao) > 0.f) { s.c = a; s.numPoints = 2; dir = crossABA(ab, ao); return 1; }
+			s.c = a; dir = abd; return 1;
+		}
+		{
+			if (!second && dot(cross(adc, ac), ao) > 0.f) { s.b = a; s.numPoints = 2; dir = crossABA(ac, ao); return 1; }
+			if (dot(cross(ad, adc), ao) > 0.f) { s.b = a; s.c = s.d; s.numPoints = 2; dir = crossABA(ad, ao); return 1; }
+			s.b = a; dir = adc; return 1;
+		}
+	}
+	return 2;
+}
+
+MI_DEV bool gjkCapsuleBox(const Capsule& c, const Box& b, GjkSimplex& sx)
+{
+	V3 dir = v3(1.f, 0.1f, -0.2f);
+	sx.c = supportCB(c, b, dir);
+	if (dot(sx.c.mk, dir) < 0.f) return false;
+	dir = -sx.c.mk;
+	sx.b = supportCB(c, b, dir);
+	if (dot(sx.b.mk, dir) < 0.f) return false;
+	dir = crossABA(sx.c.mk - sx.b.mk, -sx.b.mk);
+	sx.numPoints = 2;
+	for (u32 it = 0; it < GJK_MAX_ITERATIONS; ++it)
+	{
+		if (sqlen(dir) < 0.0001f) return false;
+		SupportPoint a = supportCB(c, b, dir);
+		if (dot(a.mk, dir) < 0.f) return false;
+		int res = updateGJKSimplex(sx, a, dir);
+		if (res == 0) { sx.a = a; sx.numPoints = 4; return true; }
+		if (res == 2) return false;
+	}
+	return false;
+}
+
+struct EpaTri { u8 a, b, c, eA, eB, eC; u8 active, pad; V3 normal; float dist; };
+struct EpaEdge { u8 a, b, tA, tB; };
+struct Epa
+{
+	SupportPoint points[EPA_MAX_POINTS];
+	EpaTri tris[EPA_MAX_TRIANGLES];
+	EpaEdge edges[EPA_MAX_EDGES];
+	u32 numTris, numPoints, numEdges;
+};
+#define EPA_NONE 0xFFu
+
+MI_DEV void epaTriInfo(const SupportPoint& a, const SupportPoint& b, const SupportPoint& c, V3& normal, float& dist)
+{
+	normal = normalize(cross(b.mk - a.mk, c.mk - a.mk));
+	dist = dot(normal, a.mk);
+}
+MI_DEV u32 epaPushTri(Epa& e, u32 a, u32 b, u32 c, u32 eA, u32 eB, u32 eC, V3 normal, float dist)
+{
+	if (e.numTris >= EPA_MAX_TRIANGLES) return EPA_NONE;
+	u32 i = e.numTris++;
+	EpaTri& t = e.tris[i];
+	t.a = (u8)a; t.b = (u8)b; t.c = (u8)c; t.eA = (u8)eA; t.eB = (u8)eB; t.eC = (u8)eC; t.active = 1; t.normal = normal; t.dist = dist;
+	return i;
+}
+MI_DEV u32 epaPushEdge(Epa& e, u32 a, u32 b, u32 tA, u32 tB)
+{
+	if (e.numEdges >= EPA_MAX_EDGES) return EPA_NONE;
+	u32 i = e.numEdges++;
+	EpaEdge& ed = e.edges[i]; ed.a = (u8)a; ed.b = (u8)b; ed.tA = (u8)tA; ed.tB = (u8)tB;
+	return i;
+}
+MI_DEV bool epaAddPoint(Epa& e, const SupportPoint& np) // collision_epa.cpp:111-239
+{
+	u8 refs[EPA_MAX_EDGES];
+	for (u32 i = 0; i < e.numEdges; ++i) refs[i] = 0;
+	for (u32 i = 0; i < e.numTris; ++i)
+	{
+		EpaTri& t = e.tris[i];
+		if (t.active)
+		{
+			float d = dot(t.normal, np.mk - e.points[t.a].mk);
+			if (d > 0.f) { ++refs[t.eA]; ++refs[t.eB]; ++refs[t.eC]; t.active = 0; }
+		}
+	}
+	u8 border[EPA_MAX_BORDER];
+	u32 nBorder = 0;
+	for (u32 i = 0; i < e.numEdges; ++i)
+	{
+		if (refs[i] == 1) { if (nBorder >= EPA_MAX_BORDER) return false; border[nBorder++] = (u8)i; }
+	}
+	u8 newEdgePerPoint[EPA_MAX_POINTS];
+	if (e.numPoints >= EPA_MAX_POINTS) return false;
+	u32 newPoint = e.numPoints++;
+	e.points[newPoint] = np;
+	u32 triOffset = e.numTris;
+	for (u32 i = 0; i < nBorder; ++i)
+	{
+		u32 ei = border[i];
+		EpaEdge& edge = e.edges[ei];
+		bool triAActive = e.tris[edge.tA].active != 0;
+		bool triBActive = e.tris[edge.tB].active != 0;
+		u32 pointToConnect = triBActive ? edge.a : edge.b;
+		u32 triIndex = e.numTris;
+		u32 newEdge = epaPushEdge(e, pointToConnect, newPoint, EPA_NONE, e.numTris);
+		if (newEdge == EPA_NONE) return false;
+		newEdgePerPoint[pointToConnect] = (u8)newEdge;
+		u32 bi = pointToConnect, ci = triBActive ? edge.b : edge.a;
+		V3 n; float dist;
+		epaTriInfo(np, e.points[bi], e.points[ci], n, dist);
+		if (epaPushTri(e, newPoint, bi, ci, ei, EPA_NONE, newEdge, n, dist) == EPA_NONE) return false;
+		if (triAActive) edge.tB = (u8)triIndex; else edge.tA = (u8)triIndex;
+	}
+	for (u32 i = 0; i < nBorder; ++i)
+	{
+		EpaEdge& edge = e.edges[border[i]];
+		bool triBNew = edge.tB >= triOffset && edge.tB != EPA_NONE;
+		u32 pointToConnect = triBNew ? edge.a : edge.b;
+		u32 other = newEdgePerPoint[pointToConnect];
+		u32 triIndex = i + triOffset;
+		e.tris[triIndex].eB = (u8)other;
+		e.edges[other].tA = (u8)triIndex;
+	}
+	return true;
+}
+MI_DEV V3 barycentric(V3 a, V3 b, V3 c, V3 p) // math.cpp:1390-1408
+{
+	V3 v0 = b - a, v1 = c - a, v2 = p - a;
+	float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+	float denom = d00 * d11 - d01 * d01;
+	denom = (fabsf(denom) < MI_EPSILON) ? 1.f : denom;
+	float v = (d11 * d20 - d01 * d21) / denom;
+	float w = (d00 * d21 - d01 * d20) / denom;
+	float u = 1.0f - v - w;
+	return v3(u, v, w);
+}
+MI_DEV void epaCapsuleBox(const GjkSimplex& g, const Capsule& c, const Box& b, V3& outPoint, V3& outNormal, float& outDepth)
+{
+	Epa e;
+	e.numTris = 0; e.numPoints = 4; e.numEdges = 0;
+	e.points[0] = g.a; e.points[1] = g.b; e.points[2] = g.c; e.points[3] = g.d;
+	V3 n; float d;
+	epaTriInfo(g.a, g.b, g.d, n, d); epaPushTri(e, 0, 1, 3, 4, 3, 0, n, d);
+	epaTriInfo(g.b, g.c, g.d, n, d); epaPushTri(e, 1, 2, 3, 5, 4, 1, n, d);
+	epaTriInfo(g.c, g.a, g.d, n, d); epaPushTri(e, 2, 0, 3, 3, 5, 2, n, d);
+	epaTriInfo(g.a, g.c, g.b, n, d); epaPushTri(e, 0, 2, 1, 1, 0, 2, n, d);
+	epaPushEdge(e, 0, 1, 0, 3); epaPushEdge(e, 1, 2, 1, 3); epaPushEdge(e, 2, 0, 2, 3);
+	epaPushEdge(e, 0, 3, 2, 0); epaPushEdge(e, 1, 3, 0, 1); epaPushEdge(e, 2, 3, 1, 2);
+	u32 closest = 0;
+	for (u32 it = 0; it < 20; ++it)
+	{
+		closest = 0xFFFFFFFFu;
+		float minD = MI_FLT_MAX;
+		for (u32 i = 0; i < e.numTris; ++i) { if (e.tris[i].active && e.tris[i].dist < minD) { minD = e.tris[i].dist; closest = i; } }
+		if (closest == 0xFFFFFFFFu) { closest = 0; break; }
+		EpaTri& tri = e.tris[closest];
+		SupportPoint a = supportCB(c, b, tri.normal);
+		float dd = dot(a.mk, tri.normal);
+		if (dd - tri.dist < 0.01f) break;
+		if (!epaAddPoint(e, a)) break;
+	}
+	EpaTri& tri = e.tris[closest];
+	const SupportPoint& pa = e.points[tri.a];
+	const SupportPoint& pb = e.points[tri.b];
+	const SupportPoint& pc = e.points[tri.c];
+	V3 bary = barycentric(pa.mk, pb.mk, pc.mk, tri.normal * tri.dist);
+	V3 pointA = bary.x * pa.a + bary.y * pb.a + bary.z * pc.a;
+	V3 pointB = bary.x * pa.b + bary.y * pb.b + bary.z * pc.b;
+	outPoint = 0.5f * (pointA + pointB);
+	outNormal = tri.normal;
+	outDepth = tri.dist;
+}
+
+MI_DEV bool capsuleBox(const Capsule& c, const Box& a, Man& m) // collision_narrow.cpp:705-769
+{
+	GjkSimplex sx;
+	if (!gjkCapsuleBox(c, a, sx)) return false;
+	V3 point, normal; float depth;
+	epaCapsuleBox(sx, c, a, point, normal, depth);
+	m.n = normal; m.count = 1;
+	m.p[0] = make_float4(point.x, point.y, point.z, depth);
+	if (fabsf(normal.x) > 0.99f || fabsf(normal.y) > 0.99f || fabsf(normal.z) > 0.99f)
+	{
+		V3 axis = normalize(c.b - c.a);
+		if (fabsf(dot(normal, axis)) < 0.01f)
+		{
+			V3 cpp[4], cpn[4];
+			float4 clipPlanes[4];
+			V3 aabbNormal = -normal;
+			V3 refPoint = v3((aabbNormal.x < 0.f) ? a.lo.x : a.hi.x, (aabbNormal.y < 0.f) ? a.lo.y : a.hi.y, (aabbNormal.z < 0.f) ? a.lo.z : a.hi.z); // getAABBReferencePlane :291-299
+			float4 referencePlane = createPlane(refPoint, aabbNormal);
+			Poly polygon; polygon.n = 2;
+			V3 pa = c.a + normal * c.r, pb = c.b + normal * c.r;
+			polygon.pts[0] = make_float4(pa.x, pa.y, pa.z, -signedDistanceToPlane(pa, referencePlane));
+			polygon.pts[1] = make_float4(pb.x, pb.y, pb.z, -signedDistanceToPlane(pb, referencePlane));
+			V3 aCenter = boxCenter(a);
+			getAABBClippingPlanes(boxRadius(a), aabbNormal, cpp, cpn);
+			for (u32 i = 0; i < 4; ++i) clipPlanes[i] = createPlane(cpp[i] + aCenter, cpn[i]);
+			clipPointsAndBuildContact(polygon, clipPlanes, referencePlane, m);
+		}
+	}
+	return true;
+}
+MI_DEV bool capsuleObb(const Capsule& c, const Obb& o, Man& m) // :771-790
+{
+	Box aabb; aabb.lo = o.c - o.r; aabb.hi = o.c + o.r;
+	Capsule c_; c_.a = conjugate(o.q) * (c.a - o.c) + o.c; c_.b = conjugate(o.q) * (c.b - o.c) + o.c; c_.r = c.r;
+	if (capsuleBox(c_, aabb, m))
+	{
+		m.n = o.q * m.n;
+		for (u32 i = 0; i < m.count; ++i)
+		{
+			V3 pt = o.q * (v3f4(m.p[i]) - o.c) + o.c;
+			m.p[i] = make_float4(pt.x, pt.y, pt.z, m.p[i].w);
+		}
+		return true;
+	}
+	return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K6/K7: pair kernels + contact emit (writeScalarContact, collision_narrow.cpp:2221-2253)
+// ---------------------------------------------------------------------------------------------------------------
+MI_DEV void writeManifold(ManifoldRec* __restrict__ out, u32 slot, const Man& m, bool hit, const ColliderRec& A, const ColliderRec& B, u32 pairIndexLo)
+{
+	ManifoldRec r;
+	u32 count = hit ? m.count : 0;
+	float friction = clamp01(sqrtf(colFriction(A) * colFriction(B)));
+	float restitution = clamp01(fmaxf(colRestitution(A), colRestitution(B)));
+	u32 fr = ((u32)(friction * 0xFFFF) << 16) | (u32)(restitution * 0xFFFF);
+	for (u32 k = 0; k < 4; ++k) r.p[k] = (k < count) ? m.p[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+	r.nf = make_float4(m.n.x, m.n.y, m.n.z, __uint_as_float(fr));
+	r.ids = make_uint4(colBody(A), colBody(B), count, pairIndexLo);
+	out[slot] = r;
+}
+
+enum { GROUP_CLOSED = 0, GROUP_BOX = 1, GROUP_GJK = 2 };
+
+template <int GROUP>
+__global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
+	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds)
+{
+	u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= counters[CTR_NUM_VALID]) return;
+	u32 key = keySorted[slot];
+	bool mine;
+	if (GROUP == GROUP_CLOSED) mine = (key == 0 || key == 1 || key == 3 || key == 4 || key == 7 || key == 21);
+	else if (GROUP == GROUP_BOX) mine = (key == 22 || key == 28);
+	else mine = (key == 9 || key == 10);
+	if (!mine) return;
+	u64 packed = pairSorted[slot];
+	u32 ia = (u32)packed, ib = (u32)(packed >> 32);
+	ColliderRec A = colWorld[ia], B = colWorld[ib];
+	Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
+	bool hit = false;
+	if (GROUP == GROUP_CLOSED)
+	{
+		switch (key)
+		{
+			case 0: hit = sphereSphere(asSphere(A), asSphere(B), m); break;
+			case 1: hit = sphereCapsule(asSphere(A), asCapsule(B), m); break;
+			case 3: hit = sphereBox(asSphere(A), asBox(B), m); break;
+			case 4: hit = sphereObb(asSphere(A), asObb(B), m); break;
+			case 7: hit = capsuleCapsule(asCapsule(A), asCapsule(B), m); break;
+			case 21: hit = boxBoxAxisAligned(asBox(A), asBox(B), m); break;
+		}
+	}
+	else if (GROUP == GROUP_BOX)
+	{
+		Obb oa;
+		if (key == 22) { Box b = asBox(A); oa.q = q4(0.f, 0.f, 0.f, 1.f); oa.c = boxCenter(b); oa.r = boxRadius(b); } // aabb -> obb (:1142-1148)
+		else oa = asObb(A);
+		hit = obbObb(oa, asObb(B), m);
+	}
+	else
+	{
+		if (key == 9) hit = capsuleBox(asCapsule(A), asBox(B), m);
+		else hit = capsuleObb(asCapsule(A), asObb(B), m);
+	}
+	writeManifold(manifolds, slot, m, hit, A, B, slot);
+}
+
+void launch_narrowphase(World& w, u32 numPairs)
+{
+	if (!numPairs) return;
+	dim3 grid((numPairs + 255) / 256), block(256);
+	hipLaunchKernelGGL(k_classify, grid, block, 0, w.stream, w.dCounters.p, w.nb, w.pairs.p, w.colWorld.p, w.pairKey.p, (u64*)w.pairsSorted.p + numPairs);
+	// sort (bucket key, packed pair): unsorted packed pairs live in the upper half of pairsSorted, sorted ones in the lower half
+	prim_sort_pairs_u32_u64(w, w.pairKey.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p + numPairs, (u64*)w.pairsSorted.p, numPairs, 6);
+	hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_CLOSED>), grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p, w.colWorld.p, w.manifolds.p);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_BOX>), dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p, w.colWorld.p, w.manifolds.p);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_GJK>), dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p, w.colWorld.p, w.manifolds.p);
+}

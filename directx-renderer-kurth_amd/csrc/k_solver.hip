@@ -1,0 +1,298 @@
+// Contact constraint pipeline on the GPU: graph colouring of contact manifolds (replaces the reference's serial greedy 8-lane
+// scheduler, constraints.cpp:51-184), contact row initialisation (constraints.cpp:3307-3379 / 3451-3616) and the projected
+// Gauss-Seidel sweep (constraints.cpp:3381-3449 / 3618-3709).
+//
+// MI355X design.  The unit of scheduling is the MANIFOLD (<= 4 contacts between one body pair): one lane owns a manifold, keeps
+// both bodies' velocities in registers across its contacts and touches each body once per sweep (2 x 32-B gather + scatter), so
+// box stacks need 4x fewer colours and body traffic than per-contact colouring.  Manifolds of one colour share no dynamic body
+// => a colour is one fully parallel launch; colours run in order.  Rows are SoA float4 planes indexed by the manifold's position
+// in (colour, contact-count) order, so every wave reads 1 KiB contiguous per plane (16 B/lane) and lanes that still have a k-th
+// contact are contiguous.  No atomics on velocities, no CAS loops; the static dummy body (index numBodies) is never written.
+#include "world.h"
+#include <rocprim/rocprim.hpp>
+
+void prim_sort_pairs_u32(World& w, const u32* kin, u32* kout, const u32* vin, u32* vout, u32 n, u32 bits);
+
+enum { CTR_NUM_PAIRS = 0, CTR_NUM_VALID = 1, CTR_NUM_MANIFOLDS = 2, CTR_NUM_CONTACTS = 3, CTR_NUM_COLORS = 4, CTR_NUM_LARGE = 5, CTR_ROUNDS_LEFT = 6, CTR_OVERFLOW = 7,
+	CTR_COLOR_START = 8 };
+
+#define UNCOLORED 0xFFFFFFFFu
+#define INACTIVE 0xFFFFFFFEu
+#define KEY_INACTIVE 0x3FFu
+
+MI_DEV u32 hash32(u32 x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+// later rounds and (pseudo-random) higher priority => smaller key; the manifold index makes keys unique
+MI_DEV u64 claimKey(u32 round, u32 m) { return ((u64)(0xFFFFu - round) << 48) | ((u64)(hash32(m * 2654435761u + round) & 0xFFFFFFu) << 24) | (u64)(m & 0xFFFFFFu); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Colouring: Luby-style rounds.  Round r: every uncoloured manifold checks whether it won BOTH of its bodies in round r-1
+// (then takes the lowest colour free at both bodies); otherwise it bids again.  Bids are 64-bit atomicMin into a per-body
+// slot, double-buffered by round parity; min() is order-independent, so the colouring is deterministic.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_color_begin(const u32* __restrict__ counters, const ManifoldRec* __restrict__ manifolds, u32* __restrict__ mColor)
+{
+	u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= counters[CTR_NUM_VALID]) return;
+	mColor[m] = manifolds[m].ids.z ? UNCOLORED : INACTIVE;
+}
+
+__global__ void __launch_bounds__(256) k_color_round(u32* __restrict__ counters, u32 nb, u32 round, u32 lastRound, const ManifoldRec* __restrict__ manifolds,
+	u32* __restrict__ mColor, u64* __restrict__ bodyMask, u64* __restrict__ claim)
+{
+	u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= counters[CTR_NUM_VALID]) return;
+	if (mColor[m] != UNCOLORED) return;
+	uint4 ids = manifolds[m].ids;
+	u32 a = ids.x, b = ids.y;
+	bool da = a < nb, db = b < nb;
+	if (round > 0)
+	{
+		const u64* prev = claim + (size_t)((round - 1) & 1) * nb;
+		u64 key = claimKey(round - 1, m);
+		bool won = (!da || prev[a] == key) && (!db || prev[b] == key);
+		if (won)
+		{
+			u64 used = (da ? bodyMask[a] : 0ull) | (db ? bodyMask[b] : 0ull);
+			u64 freeMask = ~used;
+			u32 c;
+			if (freeMask == 0ull) { c = MI_SERIAL_COLOR; }
+			else
+			{
+				c = (u32)__ffsll((long long)freeMask) - 1;
+				if (da) bodyMask[a] |= (1ull << c);
+				if (db) bodyMask[b] |= (1ull << c);
+			}
+			mColor[m] = c;
+			atomicMax(&counters[CTR_ROUNDS_LEFT], round); // last round that coloured anything (drives the adaptive round count)
+			return;
+		}
+	}
+	if (round == lastRound) // out of rounds: serial bucket keeps the step correct; the host raises the round budget
+	{
+		mColor[m] = MI_SERIAL_COLOR;
+		atomicAdd(&counters[CTR_OVERFLOW], 1u);
+		return;
+	}
+	u64* cur = claim + (size_t)(round & 1) * nb;
+	u64 key = claimKey(round, m);
+	if (da) atomicMin((unsigned long long*)&cur[a], (unsigned long long)key);
+	if (db) atomicMin((unsigned long long*)&cur[b], (unsigned long long)key);
+}
+
+__global__ void __launch_bounds__(256) k_color_keys(const u32* __restrict__ counters, u32 numPairs, const ManifoldRec* __restrict__ manifolds, const u32* __restrict__ mColor,
+	u32* __restrict__ mKey, u32* __restrict__ mIdx)
+{
+	u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= numPairs) return;
+	u32 key = KEY_INACTIVE;
+	if (m < counters[CTR_NUM_VALID])
+	{
+		u32 c = mColor[m];
+		if (c <= MI_SERIAL_COLOR) key = c * 4 + (4 - manifolds[m].ids.z);
+	}
+	mKey[m] = key;
+	mIdx[m] = m;
+}
+
+__global__ void k_color_offsets(u32* __restrict__ counters, u32 numPairs, const u32* __restrict__ keySorted)
+{
+	u32 c = threadIdx.x; // 0 .. MI_MAX_COLORS+1 (start of colour c; c = 65 -> end of the serial bucket = numManifolds)
+	__shared__ u32 starts[MI_MAX_COLORS + 2];
+	if (c < MI_MAX_COLORS + 2)
+	{
+		u32 target = (c <= MI_SERIAL_COLOR) ? c * 4 : KEY_INACTIVE;
+		u32 lo = 0, hi = numPairs;
+		while (lo < hi) { u32 mid = (lo + hi) >> 1; if (keySorted[mid] < target) lo = mid + 1; else hi = mid; }
+		starts[c] = lo;
+		counters[CTR_COLOR_START + c] = lo;
+	}
+	__syncthreads();
+	if (c == 0)
+	{
+		u32 n = 0;
+		for (u32 i = 0; i < MI_MAX_COLORS; ++i) if (starts[i + 1] > starts[i]) n = i + 1;
+		counters[CTR_NUM_COLORS] = n;
+		counters[CTR_NUM_MANIFOLDS] = starts[MI_MAX_COLORS + 1];
+	}
+}
+
+void launch_coloring(World& w, u32 numPairs)
+{
+	if (!numPairs) return;
+	dim3 grid((numPairs + 255) / 256), block(256);
+	u32 nb = w.nb;
+	MI_CHECK(hipMemsetAsync(w.bodyMask.p, 0, sizeof(u64) * (nb + 1), w.stream));
+	MI_CHECK(hipMemsetAsync(w.claim.p, 0xFF, sizeof(u64) * 2 * (nb + 1), w.stream));
+	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_ROUNDS_LEFT, 0, 2 * sizeof(u32), w.stream));
+	hipLaunchKernelGGL(k_color_begin, grid, block, 0, w.stream, w.dCounters.p, w.manifolds.p, w.mColor.p);
+	u32 rounds = w.coloringRounds;
+	for (u32 r = 0; r <= rounds; ++r)
+		hipLaunchKernelGGL(k_color_round, grid, block, 0, w.stream, w.dCounters.p, nb, r, rounds, w.manifolds.p, w.mColor.p, w.bodyMask.p, w.claim.p);
+	hipLaunchKernelGGL(k_color_keys, grid, block, 0, w.stream, w.dCounters.p, numPairs, w.manifolds.p, w.mColor.p, w.mKey.p, w.mIdx.p);
+	prim_sort_pairs_u32(w, w.mKey.p, w.mKeySorted.p, w.mIdx.p, w.mOrder.p, numPairs, 10);
+	hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(128), 0, w.stream, w.dCounters.p, numPairs, w.mKeySorted.p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K10: contact rows.  Per manifold: 96-B manifold gather + 2 x (cog 16 + invI 48 + vel 32) body gathers; writes 6 float4 planes +
+// lambda per contact, one shared float4 (normal, friction) and the id quad.  Plane p of contact k, slot s: rowPlanes[(k*6+p)*rowCap + s].
+//   p0 = rA.xyz rB.x | p1 = rB.yz t.xy | p2 = t.z JnA.xyz | p3 = JtA.xyz JnB.x | p4 = JnB.yz JtB.xy | p5 = JtB.z mN mT bias
+// ---------------------------------------------------------------------------------------------------------------
+MI_DEV M3 loadInvI(const float4* __restrict__ invIw, u32 i)
+{
+	float4 c0 = invIw[3 * i], c1 = invIw[3 * i + 1], c2 = invIw[3 * i + 2];
+	M3 I; I.m00 = c0.x; I.m10 = c0.y; I.m20 = c0.z; I.m01 = c1.x; I.m11 = c1.y; I.m21 = c1.z; I.m02 = c2.x; I.m12 = c2.y; I.m22 = c2.z;
+	return I;
+}
+
+__global__ void __launch_bounds__(256) k_contact_init(const u32* __restrict__ counters, float dt, size_t rowCap, const u32* __restrict__ mOrder,
+	const ManifoldRec* __restrict__ manifolds, const float4* __restrict__ cog, const float4* __restrict__ invIw, const float4* __restrict__ vel,
+	float4* __restrict__ rowPlanes, float4* __restrict__ rowShared, float2* __restrict__ rowLambda, uint4* __restrict__ rowIds)
+{
+	u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= counters[CTR_NUM_MANIFOLDS]) return;
+	u32 m = mOrder[s];
+	ManifoldRec man = manifolds[m];
+	u32 a = man.ids.x, b = man.ids.y, count = man.ids.z;
+	float4 ca = cog[a], cb = cog[b];
+	V3 posA = v3f4(ca), posB = v3f4(cb);
+	float invMassA = ca.w, invMassB = cb.w;
+	M3 IA = loadInvI(invIw, a), IB = loadInvI(invIw, b);
+	V3 vA = v3f4(vel[2 * a]), wA = v3f4(vel[2 * a + 1]), vB = v3f4(vel[2 * b]), wB = v3f4(vel[2 * b + 1]);
+	V3 n = v3f4(man.nf);
+	u32 fr = __float_as_uint(man.nf.w);
+	float friction = (float)(fr >> 16) / (float)0xFFFF;
+	float restitution = (float)(fr & 0xFFFF) / (float)0xFFFF;
+	float invDt = 1.f / dt;
+
+	rowShared[s] = make_float4(n.x, n.y, n.z, friction);
+	rowIds[s] = make_uint4(a, b, count, m);
+
+	for (u32 k = 0; k < count; ++k)
+	{
+		V3 point = v3f4(man.p[k]);
+		float depth = man.p[k].w;
+		V3 rA = point - posA, rB = point - posB;
+		V3 anchorVelocityA = vA + cross(wA, rA);
+		V3 anchorVelocityB = vB + cross(wB, rB);
+		V3 rel = anchorVelocityB - anchorVelocityA;
+		V3 t = noz(rel - dot(n, rel) * n);
+
+		V3 crAt = cross(rA, t), crBt = cross(rB, t);
+		float invT = invMassA + dot(crAt, IA * crAt) + invMassB + dot(crBt, IB * crBt);
+		float mT = (invT != 0.f) ? (1.f / invT) : 0.f;
+		V3 JtA = IA * crAt, JtB = IB * crBt;
+
+		V3 crAn = cross(rA, n), crBn = cross(rB, n);
+		float invN = invMassA + dot(crAn, IA * crAn) + invMassB + dot(crBn, IB * crBn);
+		float mN = (invN != 0.f) ? (1.f / invN) : 0.f;
+		float bias = 0.f;
+		if (dt > 1e-5f)
+		{
+			float vRel = dot(n, rel);
+			const float slop = -0.001f;
+			if (-depth < slop && vRel < 0.f) { bias = -restitution * vRel - 0.1f * (-depth - slop) * invDt; }
+		}
+		V3 JnA = IA * crAn, JnB = IB * crBn;
+
+		float4* P = rowPlanes + (size_t)(k * MI_ROW_PLANES) * rowCap + s;
+		P[0 * rowCap] = make_float4(rA.x, rA.y, rA.z, rB.x);
+		P[1 * rowCap] = make_float4(rB.y, rB.z, t.x, t.y);
+		P[2 * rowCap] = make_float4(t.z, JnA.x, JnA.y, JnA.z);
+		P[3 * rowCap] = make_float4(JtA.x, JtA.y, JtA.z, JnB.x);
+		P[4 * rowCap] = make_float4(JnB.y, JnB.z, JtB.x, JtB.y);
+		P[5 * rowCap] = make_float4(JtB.z, mN, mT, bias);
+		rowLambda[(size_t)k * rowCap + s] = make_float2(0.f, 0.f);
+	}
+}
+
+void launch_contact_init(World& w, u32 numPairs, float dt)
+{
+	if (!numPairs) return;
+	hipLaunchKernelGGL(k_contact_init, dim3((numPairs + 255) / 256), dim3(256), 0, w.stream, w.dCounters.p, dt, w.rowCap, w.mOrder.p, w.manifolds.p,
+		w.cog.p, w.invIw.p, w.vel.p, w.rowPlanes.p, w.rowShared.p, w.rowLambda.p, w.rowIds.p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K11: the sweep.  One lane = one manifold; friction row then normal row per contact (A.3 of SURVEY).
+// ---------------------------------------------------------------------------------------------------------------
+MI_DEV void solveManifold(u32 s, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes, const float4* __restrict__ rowShared, float2* __restrict__ rowLambda,
+	const uint4* __restrict__ rowIds, float4* __restrict__ vel)
+{
+	uint4 ids = rowIds[s];
+	u32 a = ids.x, b = ids.y, count = ids.z;
+	float4 sh = rowShared[s];
+	V3 n = v3(sh.x, sh.y, sh.z);
+	float friction = sh.w;
+	float4 la = vel[2 * a], aa = vel[2 * a + 1], lb = vel[2 * b], ab = vel[2 * b + 1];
+	V3 vA = v3f4(la), wA = v3f4(aa), vB = v3f4(lb), wB = v3f4(ab);
+	float invMassA = la.w, invMassB = lb.w;
+
+	for (u32 k = 0; k < count; ++k)
+	{
+		const float4* P = rowPlanes + (size_t)(k * MI_ROW_PLANES) * rowCap + s;
+		float4 p0 = P[0], p1 = P[rowCap], p2 = P[2 * rowCap], p3 = P[3 * rowCap], p4 = P[4 * rowCap], p5 = P[5 * rowCap];
+		float2 lam = rowLambda[(size_t)k * rowCap + s];
+		V3 rA = v3(p0.x, p0.y, p0.z), rB = v3(p0.w, p1.x, p1.y), t = v3(p1.z, p1.w, p2.x);
+		V3 JnA = v3(p2.y, p2.z, p2.w), JtA = v3(p3.x, p3.y, p3.z), JnB = v3(p3.w, p4.x, p4.y), JtB = v3(p4.z, p4.w, p5.x);
+		float mN = p5.y, mT = p5.z, bias = p5.w;
+		float impulseN = lam.x, impulseT = lam.y;
+		{ // tangent (constraints.cpp:3404-3424)
+			V3 rel = (vB + cross(wB, rB)) - (vA + cross(wA, rA));
+			float vt = dot(rel, t);
+			float lambda = -mT * vt;
+			float maxFriction = friction * impulseN;
+			float newImpulse = clampf(impulseT + lambda, -maxFriction, maxFriction);
+			lambda = newImpulse - impulseT;
+			impulseT = newImpulse;
+			V3 Pv = lambda * t;
+			vA -= invMassA * Pv; wA -= JtA * lambda;
+			vB += invMassB * Pv; wB += JtB * lambda;
+		}
+		{ // normal (constraints.cpp:3426-3442)
+			V3 rel = (vB + cross(wB, rB)) - (vA + cross(wA, rA));
+			float vn = dot(rel, n);
+			float lambda = -mN * (vn - bias);
+			float impulse = fmaxf(impulseN + lambda, 0.f);
+			lambda = impulse - impulseN;
+			impulseN = impulse;
+			V3 Pv = lambda * n;
+			vA -= invMassA * Pv; wA -= JnA * lambda;
+			vB += invMassB * Pv; wB += JnB * lambda;
+		}
+		rowLambda[(size_t)k * rowCap + s] = make_float2(impulseN, impulseT);
+	}
+	if (a < nb) { vel[2 * a] = make_float4(vA.x, vA.y, vA.z, invMassA); vel[2 * a + 1] = make_float4(wA.x, wA.y, wA.z, 0.f); }
+	if (b < nb) { vel[2 * b] = make_float4(vB.x, vB.y, vB.z, invMassB); vel[2 * b + 1] = make_float4(wB.x, wB.y, wB.z, 0.f); }
+}
+
+__global__ void __launch_bounds__(256) k_solve_color(u32 start, u32 end, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes, const float4* __restrict__ rowShared,
+	float2* __restrict__ rowLambda, const uint4* __restrict__ rowIds, float4* __restrict__ vel)
+{
+	u32 s = start + blockIdx.x * blockDim.x + threadIdx.x;
+	if (s >= end) return;
+	solveManifold(s, nb, rowCap, rowPlanes, rowShared, rowLambda, rowIds, vel);
+}
+
+// Overflow bucket: bodies with more than 64 simultaneously touching partners.  Sequential, one lane, in slot order.
+__global__ void k_solve_serial(u32 start, u32 end, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes, const float4* __restrict__ rowShared,
+	float2* __restrict__ rowLambda, const uint4* __restrict__ rowIds, float4* __restrict__ vel)
+{
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	for (u32 s = start; s < end; ++s) solveManifold(s, nb, rowCap, rowPlanes, rowShared, rowLambda, rowIds, vel);
+}
+
+// One Gauss-Seidel iteration over all contact colours.  `colorStart` is the host copy read back after colouring.
+void launch_solve_contacts_iteration(World& w, const u32* colorStart, u32 numColors)
+{
+	for (u32 c = 0; c < numColors; ++c)
+	{
+		u32 start = colorStart[c], end = colorStart[c + 1];
+		if (end <= start) continue;
+		hipLaunchKernelGGL(k_solve_color, dim3((end - start + 255) / 256), dim3(256), 0, w.stream, start, end, w.nb, w.rowCap, w.rowPlanes.p, w.rowShared.p,
+			w.rowLambda.p, w.rowIds.p, w.vel.p);
+	}
+	u32 sStart = colorStart[MI_SERIAL_COLOR], sEnd = colorStart[MI_SERIAL_COLOR + 1];
+	if (sEnd > sStart)
+		hipLaunchKernelGGL(k_solve_serial, dim3(1), dim3(64), 0, w.stream, sStart, sEnd, w.nb, w.rowCap, w.rowPlanes.p, w.rowShared.p, w.rowLambda.p, w.rowIds.p, w.vel.p);
+}

@@ -1,0 +1,133 @@
+// Host-side World of the MI355X rigid-body stepper: owns the SoA device buffers (HBM layout in DESIGN.md), one HIP
+// stream, and the per-step launch sequence.  The C-ABI in include/mi_physics.h is a thin shell over this class.
+#pragma once
+#include "mi_common.h"
+#include "../../include/mi_physics.h"
+#include <vector>
+#include <string>
+
+// ---- persistent joint PODs: byte-for-byte the reference's structs (constraints.h:73-80,129-135,175-183,229-257,346-380,497-520)
+struct mi_distance_constraint { float localAnchorA[3], localAnchorB[3], globalLength; };
+struct mi_ball_constraint { float localAnchorA[3], localAnchorB[3]; };
+struct mi_fixed_constraint { float initialInvRotationDifference[4], localAnchorA[3], localAnchorB[3]; };
+struct mi_hinge_constraint
+{
+	float localAnchorA[3], localAnchorB[3], localHingeAxisA[3], localHingeAxisB[3];
+	float minRotationLimit, maxRotationLimit, maxMotorTorque; u32 motorType; float motorVelocity;
+	float localHingeTangentA[3], localHingeBitangentA[3], localHingeTangentB[3];
+};
+struct mi_cone_twist_constraint
+{
+	float localAnchorA[3], localAnchorB[3], localLimitAxisA[3], localLimitAxisB[3];
+	float localLimitTangentA[3], localLimitBitangentA[3], localLimitTangentB[3];
+	float swingLimit, twistLimit; u32 swingMotorType; float swingMotorVelocity, maxSwingMotorTorque, swingMotorAxis;
+	u32 twistMotorType; float twistMotorVelocity, maxTwistMotorTorque;
+};
+struct mi_slider_constraint
+{
+	float initialInvRotationDifference[4], localAnchorA[3], localAnchorB[3], localAxisA[3];
+	float negDistanceLimit, posDistanceLimit, maxMotorForce; u32 motorType; float motorVelocity;
+};
+static_assert(sizeof(mi_distance_constraint) == 28 && sizeof(mi_ball_constraint) == 24 && sizeof(mi_fixed_constraint) == 40, "POD layout");
+static_assert(sizeof(mi_hinge_constraint) == 104 && sizeof(mi_cone_twist_constraint) == 120 && sizeof(mi_slider_constraint) == 72, "POD layout");
+
+static const u32 MI_JOINT_TYPES = 6;
+static const u32 MI_JOINT_POD_SIZE[MI_JOINT_TYPES] = { 28, 24, 40, 104, 120, 72 };
+// Per-joint solver scratch ("update" record) in floats, by type; laid out by the kernels in k_joints.hip.
+static const u32 MI_JOINT_UPDATE_FLOATS[MI_JOINT_TYPES] = { 20, 20, 36, 56, 80, 72 };
+
+template <typename T> struct DevBuf
+{
+	T* p = nullptr; size_t cap = 0;
+	void ensure(size_t n, hipStream_t s, bool keep = false);
+	void release();
+};
+
+struct JointSet
+{
+	std::vector<uint8_t> pods;            // host, add order
+	std::vector<u32> a, b;                // body ids
+	std::vector<uint8_t> alive;
+	// colour-sorted device view
+	DevBuf<uint8_t> dPods; DevBuf<uint2> dPairs; DevBuf<float> dUpdate;
+	std::vector<u32> order;               // sorted slot -> joint id
+	std::vector<u32> colorStart;          // size numColors+1
+	u32 count() const { return (u32)a.size(); }
+};
+
+struct StepCounters // device -> host each step (pinned)
+{
+	u32 numPairs, numValidPairs, numManifolds, numContacts, numColors, numLarge, coloringRoundsLeft, overflow;
+	u32 colorStart[MI_MAX_COLORS + 2];
+	u32 bucketStart[32];
+	float cellSize; u32 pad[3];
+};
+
+struct World
+{
+	int device = 0;
+	hipStream_t stream = nullptr;
+	int lastError = 0; std::string lastErrorText;
+
+	// ---- host mirrors (add API) ----
+	struct HBody { float pos[3], rot[4]; float localCOG[3], invMass, invInertia[9]; float gravityFactor, linDamp, angDamp; float v[3], w[3], force[3], torque[3]; std::vector<u32> colliders; };
+	struct HCollider { float shape[10]; float restitution, friction, density; u32 type, body; float spos[3], srot[4]; };
+	std::vector<HBody> bodies;
+	std::vector<HCollider> colliders;
+	JointSet joints[MI_JOINT_TYPES];
+	bool topologyDirty = true;   // bodies/colliders added since last upload
+	bool jointsDirty = true;
+	bool stateOnDevice = false;  // device holds the authoritative pose/velocity
+
+	// ---- device buffers ----
+	u32 nb = 0, nc = 0;
+	DevBuf<float4> pose, pose0, poseLerp, vel, bprops, force, cog, invIw;
+	DevBuf<ColliderRec> colLocal, colWorld;
+	DevBuf<float4> colStaticPose, aabbMin, aabbMax;
+	// broadphase
+	DevBuf<u32> hashKey, hashKeySorted, sortIdx, sortIdxSorted, cellStart, cellEnd, largeFlag, largeScan, largeList, pairCount, pairOffset;
+	DevBuf<u64> sCellKey; DevBuf<float4> sMin, sMax;
+	DevBuf<uint2> pairs;
+	u32 hashTableSize = 0;
+	// narrowphase
+	DevBuf<u32> pairKey, pairKeySorted; DevBuf<uint2> pairsSorted;
+	DevBuf<ManifoldRec> manifolds;
+	// colouring / solver
+	DevBuf<u64> bodyMask, claim; DevBuf<u32> mColor, mKey, mKeySorted, mIdx, mOrder;
+	DevBuf<float4> rowPlanes, rowShared; DevBuf<float2> rowLambda; DevBuf<uint4> rowIds;
+	DevBuf<uint8_t> tempStorage;
+	DevBuf<u32> dCounters; StepCounters* hCounters = nullptr;
+	size_t pairCap = 0, rowCap = 0;
+
+	// settings snapshot for the running step
+	u32 iterations = 30;
+	u32 coloringRounds = 24;     // adaptive: last useful round of the previous step + margin
+	mi_stats stats = {};
+	std::vector<hipEvent_t> stageEvents;
+	bool timeStages = false;
+
+	World(int dev);
+	~World();
+	void fail(int code, const std::string& what);
+	void upload();
+	void uploadJoints();
+	void downloadState();
+	int stepInternal(float dt, u32 iterations);
+	int step(float* timer, const mi_physics_settings* s, float dt);
+};
+
+// ---- launchers (one per stage; each defined next to its kernels) --------------------------------------------------
+void launch_build_colliders(World& w);
+void launch_broadphase_count(World& w);                    // grid build + pair count + scan; leaves numPairs in dCounters
+void launch_broadphase_write(World& w, u32 numPairs);
+void launch_narrowphase(World& w, u32 numPairs);
+void launch_integrate_forces(World& w, float dt);
+void launch_coloring(World& w, u32 numPairs);
+void launch_contact_init(World& w, u32 numPairs, float dt);
+void launch_solve_contacts_iteration(World& w, const u32* colorStart, u32 numColors);
+void launch_integrate_velocities(World& w, float dt);
+void launch_joint_init(World& w, float dt);
+void launch_joint_solve_iteration(World& w);
+void launch_copy_pose0(World& w);
+void launch_lerp_pose(World& w, float t);
+size_t primitives_temp_bytes(size_t maxItems);

@@ -1,0 +1,840 @@
+// World: host mirror of the add API, HBM buffer management, the per-step launch sequence and the C-ABI of include/mi_physics.h.
+// Step order follows the reference's physicsStepInternal (physics.cpp:1180-1362) exactly: world-space colliders from the
+// previous step's physics_transform1 -> broadphase -> narrowphase -> gravity/force integration -> constraint init (with
+// post-gravity velocities) -> N solver iterations (joints by type, then contacts) -> velocity integration.
+#include "world.h"
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+#include <map>
+
+static thread_local std::string g_createError;
+static thread_local World* g_currentWorld = nullptr;
+
+void mi_set_error(hipError_t e, const char* file, int line)
+{
+	char buf[512];
+	snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+	if (g_currentWorld) { if (!g_currentWorld->lastError) { g_currentWorld->lastError = MI_ERR_HIP; g_currentWorld->lastErrorText = buf; } }
+	else g_createError = buf;
+}
+
+template <typename T> void DevBuf<T>::ensure(size_t n, hipStream_t s, bool keep)
+{
+	if (n <= cap) return;
+	size_t newCap = std::max(n, cap + cap / 2);
+	T* np = nullptr;
+	MI_CHECK(hipMalloc((void**)&np, newCap * sizeof(T)));
+	if (keep && p && cap) { MI_CHECK(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s)); MI_CHECK(hipStreamSynchronize(s)); }
+	if (p) MI_CHECK(hipFree(p));
+	p = np; cap = newCap;
+}
+template <typename T> void DevBuf<T>::release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+
+template struct DevBuf<float4>; template struct DevBuf<float2>; template struct DevBuf<uint2>; template struct DevBuf<uint4>; template struct DevBuf<u32>;
+template struct DevBuf<u64>; template struct DevBuf<uint8_t>; template struct DevBuf<float>; template struct DevBuf<ColliderRec>; template struct DevBuf<ManifoldRec>;
+
+World::World(int dev) : device(dev)
+{
+	g_currentWorld = this;
+	MI_CHECK(hipSetDevice(dev));
+	MI_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+	MI_CHECK(hipHostMalloc((void**)&hCounters, sizeof(StepCounters) + 64, hipHostMallocDefault));
+	if (hCounters) memset(hCounters, 0, sizeof(StepCounters) + 64);
+	dCounters.ensure(256, stream);
+	if (dCounters.p) MI_CHECK(hipMemsetAsync(dCounters.p, 0, 256 * sizeof(u32), stream));
+	stageEvents.resize(8);
+	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
+}
+
+World::~World()
+{
+	g_currentWorld = this;
+	if (stream) (void)hipStreamSynchronize(stream);
+	DevBuf<float4>* f4[] = { &pose, &pose0, &poseLerp, &vel, &bprops, &force, &cog, &invIw, &colStaticPose, &aabbMin, &aabbMax, &sMin, &sMax, &rowPlanes, &rowShared };
+	for (auto b : f4) b->release();
+	DevBuf<u32>* u4[] = { &hashKey, &hashKeySorted, &sortIdx, &sortIdxSorted, &cellStart, &cellEnd, &largeFlag, &largeScan, &largeList, &pairCount, &pairOffset, &pairKey, &pairKeySorted,
+		&mColor, &mKey, &mKeySorted, &mIdx, &mOrder, &dCounters };
+	for (auto b : u4) b->release();
+	colLocal.release(); colWorld.release(); sCellKey.release(); pairs.release(); pairsSorted.release(); manifolds.release(); bodyMask.release(); claim.release();
+	rowLambda.release(); rowIds.release(); tempStorage.release();
+	for (auto& js : joints) { js.dPods.release(); js.dPairs.release(); js.dUpdate.release(); }
+	for (auto& e : stageEvents) if (e) (void)hipEventDestroy(e);
+	if (hCounters) (void)hipHostFree(hCounters);
+	if (stream) (void)hipStreamDestroy(stream);
+	g_currentWorld = nullptr;
+}
+
+void World::fail(int code, const std::string& what) { if (!lastError) { lastError = code; lastErrorText = what; } }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Mass properties on the host at add time — reference physics.cpp:1416-1519 (per collider) + rigid_body.cpp:29-81 (combine).
+// ---------------------------------------------------------------------------------------------------------------
+struct MassProps { M3 inertia; V3 cog; float mass; };
+
+static M3 mzero() { M3 r; memset(&r, 0, sizeof(r)); return r; }
+static M3 mscaleH(const M3& a, float s) { M3 r; const float* p = &a.m00; float* q = &r.m00; for (int i = 0; i < 9; ++i) q[i] = p[i] * s; return r; }
+static M3 msub(const M3& a, const M3& b) { M3 r; const float* p = &a.m00; const float* q = &b.m00; float* o = &r.m00; for (int i = 0; i < 9; ++i) o[i] = p[i] - q[i]; return r; }
+static M3 mouter(V3 a, V3 b)
+{
+	V3 c0 = a * b.x, c1 = a * b.y, c2 = a * b.z;
+	M3 r; r.m00 = c0.x; r.m10 = c0.y; r.m20 = c0.z; r.m01 = c1.x; r.m11 = c1.y; r.m21 = c1.z; r.m02 = c2.x; r.m12 = c2.y; r.m22 = c2.z;
+	return r;
+}
+static M3 minvert(const M3& m) // math.cpp:276-306
+{
+	M3 inv;
+	inv.m00 = m.m11 * m.m22 - m.m21 * m.m12; inv.m01 = m.m02 * m.m21 - m.m22 * m.m01; inv.m02 = m.m01 * m.m12 - m.m11 * m.m02;
+	inv.m10 = m.m12 * m.m20 - m.m22 * m.m10; inv.m11 = m.m00 * m.m22 - m.m20 * m.m02; inv.m12 = m.m02 * m.m10 - m.m12 * m.m00;
+	inv.m20 = m.m10 * m.m21 - m.m20 * m.m11; inv.m21 = m.m01 * m.m20 - m.m21 * m.m00; inv.m22 = m.m00 * m.m11 - m.m10 * m.m01;
+	float det = m.m00 * (m.m11 * m.m22 - m.m21 * m.m12) - m.m01 * (m.m10 * m.m22 - m.m20 * m.m12) + m.m02 * (m.m10 * m.m21 - m.m20 * m.m11);
+	if (det == 0.f) return mzero();
+	return mscaleH(inv, 1.f / det);
+}
+
+static MassProps colliderMassProps(const World::HCollider& c)
+{
+	MassProps r; r.inertia = mzero(); r.cog = v3s(0.f); r.mass = 0.f;
+	const float* s = c.shape;
+	switch (c.type)
+	{
+		case MI_SPHERE:
+		{
+			float radius = s[3];
+			float sqRadiusPI = MI_PI * (radius * radius);
+			r.mass = (4.f / 3.f * sqRadiusPI * radius) * c.density;
+			r.cog = v3(s[0], s[1], s[2]);
+			r.inertia = mscaleH(midentity(), 2.f / 5.f * r.mass * radius * radius);
+		} break;
+		case MI_CAPSULE:
+		{
+			V3 pA = v3(s[0], s[1], s[2]), pB = v3(s[3], s[4], s[5]); float radius = s[6];
+			V3 axis = pA - pB;
+			if (axis.y < 0.f) axis *= -1.f;
+			float height = length(axis);
+			axis *= (1.f / height);
+			M3 rot = quaternionToMat3(rotateFromTo(v3(0.f, 1.f, 0.f), axis));
+			float sqRadius = radius * radius;
+			float sqRadiusPI = MI_PI * sqRadius;
+			float volume = 4.f / 3.f * sqRadiusPI * radius + sqRadiusPI * length(pA - pB);
+			r.mass = volume * c.density;
+			r.cog = (pA + pB) * 0.5f;
+			float cylinderMass = c.density * sqRadiusPI * height;
+			float hemiSphereMass = c.density * 2.f / 3.f * sqRadiusPI * radius;
+			float sqCapsuleHeight = height * height;
+			M3 I = mzero();
+			I.m11 = sqRadius * cylinderMass * 0.5f;
+			I.m00 = I.m22 = I.m11 * 0.5f + cylinderMass * sqCapsuleHeight / 12.f;
+			float temp0 = hemiSphereMass * 2.f * sqRadius / 5.f;
+			I.m11 += temp0 * 2.f;
+			float temp1 = height * 0.5f;
+			float temp2 = temp0 + hemiSphereMass * (temp1 * temp1 + 3.f / 8.f * sqCapsuleHeight);
+			I.m00 += temp2 * 2.f;
+			I.m22 += temp2 * 2.f;
+			r.inertia = mtranspose(rot) * I * rot;
+		} break;
+		case MI_AABB:
+		{
+			V3 lo = v3(s[0], s[1], s[2]), hi = v3(s[3], s[4], s[5]);
+			V3 d0 = hi - lo;
+			r.mass = (d0.x * d0.y * d0.z) * c.density;
+			r.cog = (lo + hi) * 0.5f;
+			V3 d = ((hi - lo) * 0.5f) * 2.f;
+			r.inertia.m00 = 1.f / 12.f * r.mass * (d.y * d.y + d.z * d.z);
+			r.inertia.m11 = 1.f / 12.f * r.mass * (d.x * d.x + d.z * d.z);
+			r.inertia.m22 = 1.f / 12.f * r.mass * (d.x * d.x + d.y * d.y);
+		} break;
+		case MI_OBB:
+		{
+			Q4 q = q4(s[0], s[1], s[2], s[3]); V3 radius = v3(s[7], s[8], s[9]);
+			V3 d = radius * 2.f;
+			r.mass = (d.x * d.y * d.z) * c.density;
+			r.cog = v3(s[4], s[5], s[6]);
+			M3 I = mzero();
+			I.m00 = 1.f / 12.f * r.mass * (d.y * d.y + d.z * d.z);
+			I.m11 = 1.f / 12.f * r.mass * (d.x * d.x + d.z * d.z);
+			I.m22 = 1.f / 12.f * r.mass * (d.x * d.x + d.y * d.y);
+			M3 rot = quaternionToMat3(q);
+			r.inertia = mtranspose(rot) * I * rot;
+		} break;
+		default: break;
+	}
+	return r;
+}
+
+static void recalculateProperties(World& w, World::HBody& rb) // rigid_body.cpp:29-81
+{
+	if (rb.invMass == 0.f) return;
+	u32 n = (u32)rb.colliders.size();
+	if (!n) return;
+	std::vector<MassProps> props(n);
+	for (u32 i = 0; i < n; ++i) props[i] = colliderMassProps(w.colliders[rb.colliders[n - 1 - i]]); // newest first (scene.h:56-58)
+	M3 inertia = mzero(); V3 cog = v3s(0.f); float mass = 0.f;
+	for (u32 i = 0; i < n; ++i) { mass += props[i].mass; cog += props[i].cog * props[i].mass; }
+	rb.invMass = 1.f / mass;
+	cog = cog * rb.invMass;
+	rb.localCOG[0] = cog.x; rb.localCOG[1] = cog.y; rb.localCOG[2] = cog.z;
+	for (u32 i = 0; i < n; ++i)
+	{
+		V3 r = props[i].cog - cog;
+		inertia = madd(inertia, madd(props[i].inertia, mscaleH(msub(mscaleH(midentity(), dot(r, r)), mouter(r, r)), props[i].mass)));
+	}
+	M3 inv = minvert(inertia);
+	memcpy(rb.invInertia, &inv.m00, 36);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Upload / download
+// ---------------------------------------------------------------------------------------------------------------
+static u32 nextPow2(u32 v) { u32 p = 1; while (p < v) p <<= 1; return p; }
+
+void World::downloadState()
+{
+	if (!stateOnDevice || !nb) return;
+	std::vector<float4> hp(2 * (size_t)nb), hv(2 * (size_t)nb), hf(2 * (size_t)nb);
+	MI_CHECK(hipMemcpyAsync(hp.data(), pose.p, sizeof(float4) * hp.size(), hipMemcpyDeviceToHost, stream));
+	MI_CHECK(hipMemcpyAsync(hv.data(), vel.p, sizeof(float4) * hv.size(), hipMemcpyDeviceToHost, stream));
+	MI_CHECK(hipMemcpyAsync(hf.data(), force.p, sizeof(float4) * hf.size(), hipMemcpyDeviceToHost, stream));
+	MI_CHECK(hipStreamSynchronize(stream));
+	for (u32 i = 0; i < nb; ++i)
+	{
+		HBody& b = bodies[i];
+		b.pos[0] = hp[2 * i].x; b.pos[1] = hp[2 * i].y; b.pos[2] = hp[2 * i].z;
+		b.rot[0] = hp[2 * i + 1].x; b.rot[1] = hp[2 * i + 1].y; b.rot[2] = hp[2 * i + 1].z; b.rot[3] = hp[2 * i + 1].w;
+		b.v[0] = hv[2 * i].x; b.v[1] = hv[2 * i].y; b.v[2] = hv[2 * i].z;
+		b.w[0] = hv[2 * i + 1].x; b.w[1] = hv[2 * i + 1].y; b.w[2] = hv[2 * i + 1].z;
+		b.force[0] = hf[2 * i].x; b.force[1] = hf[2 * i].y; b.force[2] = hf[2 * i].z;
+		b.torque[0] = hf[2 * i + 1].x; b.torque[1] = hf[2 * i + 1].y; b.torque[2] = hf[2 * i + 1].z;
+	}
+}
+
+void World::upload()
+{
+	if (!topologyDirty) return;
+	if (stateOnDevice) downloadState(); // bodies added mid-simulation: pull the live state first
+	u32 newNb = (u32)bodies.size(), newNc = (u32)colliders.size();
+	std::vector<float4> hp(2 * (size_t)newNb), hv(2 * ((size_t)newNb + 1)), hprops(5 * (size_t)newNb), hf(2 * (size_t)newNb);
+	for (u32 i = 0; i < newNb; ++i)
+	{
+		const HBody& b = bodies[i];
+		hp[2 * i] = make_float4(b.pos[0], b.pos[1], b.pos[2], 0.f);
+		hp[2 * i + 1] = make_float4(b.rot[0], b.rot[1], b.rot[2], b.rot[3]);
+		hv[2 * i] = make_float4(b.v[0], b.v[1], b.v[2], b.invMass);
+		hv[2 * i + 1] = make_float4(b.w[0], b.w[1], b.w[2], 0.f);
+		hprops[5 * i] = make_float4(b.localCOG[0], b.localCOG[1], b.localCOG[2], b.invMass);
+		hprops[5 * i + 1] = make_float4(b.invInertia[0], b.invInertia[1], b.invInertia[2], 0.f);
+		hprops[5 * i + 2] = make_float4(b.invInertia[3], b.invInertia[4], b.invInertia[5], 0.f);
+		hprops[5 * i + 3] = make_float4(b.invInertia[6], b.invInertia[7], b.invInertia[8], 0.f);
+		hprops[5 * i + 4] = make_float4(b.gravityFactor, b.linDamp, b.angDamp, 0.f);
+		hf[2 * i] = make_float4(b.force[0], b.force[1], b.force[2], 0.f);
+		hf[2 * i + 1] = make_float4(b.torque[0], b.torque[1], b.torque[2], 0.f);
+	}
+	hv[2 * (size_t)newNb] = make_float4(0.f, 0.f, 0.f, 0.f); hv[2 * (size_t)newNb + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+	std::vector<ColliderRec> hc(newNc); std::vector<float4> hsp(2 * (size_t)newNc);
+	for (u32 i = 0; i < newNc; ++i)
+	{
+		const HCollider& c = colliders[i];
+		ColliderRec r;
+		r.a = make_float4(c.shape[0], c.shape[1], c.shape[2], c.shape[3]);
+		r.b = make_float4(c.shape[4], c.shape[5], c.shape[6], c.shape[7]);
+		r.c = make_float4(c.shape[8], c.shape[9], c.restitution, c.friction);
+		u32 body = (c.body == MI_STATIC_BODY) ? newNb : c.body;
+		r.d = make_float4(mi_u2f(c.type), mi_u2f(body), c.density, 0.f);
+		hc[i] = r;
+		hsp[2 * i] = make_float4(c.spos[0], c.spos[1], c.spos[2], 0.f);
+		hsp[2 * i + 1] = make_float4(c.srot[0], c.srot[1], c.srot[2], c.srot[3]);
+	}
+
+	nb = newNb; nc = newNc;
+	size_t nb1 = (size_t)nb + 1;
+	pose.ensure(2 * nb1, stream); pose0.ensure(2 * nb1, stream); poseLerp.ensure(2 * nb1, stream); vel.ensure(2 * nb1, stream);
+	bprops.ensure(5 * nb1, stream); force.ensure(2 * nb1, stream); cog.ensure(nb1, stream); invIw.ensure(3 * nb1, stream);
+	bodyMask.ensure(nb1, stream); claim.ensure(2 * nb1, stream);
+	size_t ncap = std::max<size_t>(nc, 1);
+	colLocal.ensure(ncap, stream); colWorld.ensure(ncap, stream); colStaticPose.ensure(2 * ncap, stream); aabbMin.ensure(ncap, stream); aabbMax.ensure(ncap, stream);
+	hashKey.ensure(ncap, stream); hashKeySorted.ensure(ncap, stream); sortIdx.ensure(ncap, stream); sortIdxSorted.ensure(ncap, stream);
+	sCellKey.ensure(ncap, stream); sMin.ensure(ncap, stream); sMax.ensure(ncap, stream); pairCount.ensure(ncap + 1, stream); pairOffset.ensure(ncap + 1, stream);
+	hashTableSize = std::max(1024u, nextPow2(2 * nc));
+	cellStart.ensure(hashTableSize, stream); cellEnd.ensure(hashTableSize, stream);
+
+	if (nb)
+	{
+		MI_CHECK(hipMemcpyAsync(pose.p, hp.data(), sizeof(float4) * hp.size(), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipMemcpyAsync(pose0.p, hp.data(), sizeof(float4) * hp.size(), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipMemcpyAsync(poseLerp.p, hp.data(), sizeof(float4) * hp.size(), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipMemcpyAsync(bprops.p, hprops.data(), sizeof(float4) * hprops.size(), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipMemcpyAsync(force.p, hf.data(), sizeof(float4) * hf.size(), hipMemcpyHostToDevice, stream));
+	}
+	MI_CHECK(hipMemcpyAsync(vel.p, hv.data(), sizeof(float4) * hv.size(), hipMemcpyHostToDevice, stream));
+	if (nc)
+	{
+		MI_CHECK(hipMemcpyAsync(colLocal.p, hc.data(), sizeof(ColliderRec) * hc.size(), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipMemcpyAsync(colStaticPose.p, hsp.data(), sizeof(float4) * hsp.size(), hipMemcpyHostToDevice, stream));
+	}
+	MI_CHECK(hipStreamSynchronize(stream));
+	topologyDirty = false; stateOnDevice = true;
+	jointsDirty = true; // the static dummy index (= nb) moved
+}
+
+// Greedy colouring of each joint type on the host (joints change rarely): joint i gets the lowest colour free at both bodies.
+void World::uploadJoints()
+{
+	if (!jointsDirty) return;
+	for (u32 t = 0; t < MI_JOINT_TYPES; ++t)
+	{
+		JointSet& js = joints[t];
+		u32 n = js.count(), podSize = MI_JOINT_POD_SIZE[t];
+		std::vector<u32> color(n, 0xFFFFFFFFu);
+		std::map<u32, std::vector<bool>> used;
+		u32 numColors = 0;
+		for (u32 i = 0; i < n; ++i)
+		{
+			if (!js.alive[i]) continue;
+			std::vector<bool>& ua = used[js.a[i]]; std::vector<bool>& ub = used[js.b[i]];
+			u32 c = 0;
+			for (;; ++c) { bool fa = c < ua.size() && ua[c], fb = c < ub.size() && ub[c]; if (!fa && !fb) break; }
+			if (ua.size() <= c) ua.resize(c + 1, false);
+			ua[c] = true;
+			std::vector<bool>& ub2 = used[js.b[i]];
+			if (ub2.size() <= c) ub2.resize(c + 1, false);
+			ub2[c] = true;
+			color[i] = c; numColors = std::max(numColors, c + 1);
+		}
+		js.order.clear(); js.colorStart.assign(1, 0);
+		for (u32 c = 0; c < numColors; ++c)
+		{
+			for (u32 i = 0; i < n; ++i) if (color[i] == c) js.order.push_back(i);
+			js.colorStart.push_back((u32)js.order.size());
+		}
+		u32 m = (u32)js.order.size();
+		if (!m) continue;
+		std::vector<uint8_t> hp((size_t)m * podSize); std::vector<uint2> hpr(m);
+		for (u32 s = 0; s < m; ++s)
+		{
+			u32 i = js.order[s];
+			memcpy(hp.data() + (size_t)s * podSize, js.pods.data() + (size_t)i * podSize, podSize);
+			hpr[s] = make_uint2(js.a[i], js.b[i]);
+		}
+		js.dPods.ensure(hp.size(), stream); js.dPairs.ensure(m, stream); js.dUpdate.ensure((size_t)m * MI_JOINT_UPDATE_FLOATS[t], stream);
+		MI_CHECK(hipMemcpyAsync(js.dPods.p, hp.data(), hp.size(), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipMemcpyAsync(js.dPairs.p, hpr.data(), sizeof(uint2) * m, hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipStreamSynchronize(stream));
+	}
+	jointsDirty = false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One physicsStepInternal
+// ---------------------------------------------------------------------------------------------------------------
+static void ensurePairBuffers(World& w, size_t numPairs)
+{
+	if (numPairs <= w.pairCap) return;
+	size_t cap = std::max<size_t>(numPairs + numPairs / 2, 4096);
+	w.pairs.ensure(cap, w.stream, true); w.pairsSorted.ensure(2 * cap, w.stream); w.pairKey.ensure(cap, w.stream); w.pairKeySorted.ensure(cap, w.stream);
+	w.manifolds.ensure(cap, w.stream); w.mColor.ensure(cap, w.stream); w.mKey.ensure(cap, w.stream); w.mKeySorted.ensure(cap, w.stream); w.mIdx.ensure(cap, w.stream); w.mOrder.ensure(cap, w.stream);
+	w.rowPlanes.ensure((size_t)MI_MAX_CONTACTS_PER_MANIFOLD * MI_ROW_PLANES * cap, w.stream); w.rowShared.ensure(cap, w.stream);
+	w.rowLambda.ensure((size_t)MI_MAX_CONTACTS_PER_MANIFOLD * cap, w.stream); w.rowIds.ensure(cap, w.stream);
+	w.pairCap = cap; w.rowCap = cap;
+}
+
+static void readCounters(World& w)
+{
+	MI_CHECK(hipMemcpyAsync(w.hCounters, w.dCounters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, w.stream));
+	MI_CHECK(hipStreamSynchronize(w.stream));
+}
+
+int World::stepInternal(float dt, u32 iters)
+{
+	g_currentWorld = this;
+	if (lastError) return lastError;
+	upload(); uploadJoints();
+	if (lastError) return lastError;
+	if (!nb) return MI_OK;
+	iterations = iters;
+	bool T = timeStages;
+	if (T) MI_CHECK(hipEventRecord(stageEvents[0], stream));
+
+	launch_build_colliders(*this);
+	launch_broadphase_count(*this);
+	readCounters(*this);                                   // sync #1: number of overlapping pairs
+	u32 numPairs = hCounters->numPairs;
+	ensurePairBuffers(*this, numPairs);
+	launch_broadphase_write(*this, numPairs);
+	if (T) MI_CHECK(hipEventRecord(stageEvents[1], stream));
+
+	launch_narrowphase(*this, numPairs);
+	if (T) MI_CHECK(hipEventRecord(stageEvents[2], stream));
+
+	launch_integrate_forces(*this, dt);
+	launch_coloring(*this, numPairs);
+	launch_contact_init(*this, numPairs, dt);
+	launch_joint_init(*this, dt);
+	u32 numColors = 0;
+	if (numPairs)
+	{
+		readCounters(*this);                               // sync #2: colour boundaries of the contact schedule
+		numColors = hCounters->numColors;
+		// adaptive colouring budget: last round that made progress + margin; grow quickly on overflow
+		u32 lastUseful = hCounters->coloringRoundsLeft;
+		coloringRounds = hCounters->overflow ? std::min(1024u, coloringRounds * 2) : std::max(12u, lastUseful + 6);
+	}
+	else { memset(hCounters->colorStart, 0, sizeof(hCounters->colorStart)); hCounters->numManifolds = 0; hCounters->numValidPairs = 0; }
+	if (T) MI_CHECK(hipEventRecord(stageEvents[3], stream));
+
+	for (u32 it = 0; it < iters; ++it)                     // solveOneIteration (constraints.cpp:3748-3772)
+	{
+		launch_joint_solve_iteration(*this);
+		if (numPairs) launch_solve_contacts_iteration(*this, hCounters->colorStart, numColors);
+	}
+	if (T) MI_CHECK(hipEventRecord(stageEvents[4], stream));
+
+	launch_integrate_velocities(*this, dt);
+	if (T) MI_CHECK(hipEventRecord(stageEvents[5], stream));
+
+	stats.numRigidBodies = nb; stats.numColliders = nc; stats.numBroadphaseOverlaps = numPairs;
+	stats.numCollisions = hCounters->numManifolds; stats.numColors = numColors; stats.numInternalSteps++;
+	u32 nj = 0; for (auto& js : joints) nj += (u32)js.order.size();
+	stats.numJoints = nj;
+	if (T)
+	{
+		MI_CHECK(hipStreamSynchronize(stream));
+		float ms[5] = { 0, 0, 0, 0, 0 };
+		for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], stageEvents[i], stageEvents[i + 1]);
+		stats.msCollidersBroad = ms[0]; stats.msNarrow = ms[1]; stats.msSolverSetup = ms[2]; stats.msSolve = ms[3]; stats.msIntegrate = ms[4];
+		stats.msTotal = ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
+	}
+	return lastError;
+}
+
+// physicsStep — reference physics.cpp:1364-1413
+int World::step(float* timer, const mi_physics_settings* s, float dt)
+{
+	g_currentWorld = this;
+	upload(); uploadJoints();
+	if (lastError) return lastError;
+	if (s->fixedFrameRate)
+	{
+		const float fixedDt = 1.f / (float)s->frameRate;
+		*timer += dt;
+		u32 physicsIterations = 0;
+		if (*timer >= fixedDt)
+		{
+			launch_copy_pose0(*this);
+			while (*timer >= fixedDt && physicsIterations++ < s->maxPhysicsIterationsPerFrame)
+			{
+				int e = stepInternal(fixedDt, s->numRigidSolverIterations);
+				if (e) return e;
+				*timer -= fixedDt;
+			}
+		}
+		if (*timer >= fixedDt) *timer = fmodf(*timer, fixedDt);
+		launch_lerp_pose(*this, *timer / fixedDt);
+	}
+	else
+	{
+		int e = stepInternal(dt, s->numRigidSolverIterations);
+		if (e) return e;
+		if (nb) MI_CHECK(hipMemcpyAsync(poseLerp.p, pose.p, sizeof(float4) * 2 * nb, hipMemcpyDeviceToDevice, stream));
+	}
+	return lastError;
+}
+
+// =====================================================================================================================
+// C-ABI
+// =====================================================================================================================
+struct mi_world { World w; mi_world(int dev) : w(dev) {} };
+#define W (&world->w)
+#define CHECK_WORLD(ret) if (!world) return ret; g_currentWorld = W
+
+extern "C" {
+
+mi_world* mi_world_create(const mi_world_desc* desc)
+{
+	g_createError.clear();
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { g_createError = "no HIP device available (this library has no CPU fallback)"; return nullptr; }
+	int dev = desc ? desc->device : -1;
+	if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+	if (dev >= count) { g_createError = "device ordinal out of range"; return nullptr; }
+	mi_world* world = new mi_world(dev);
+	if (world->w.lastError) { g_createError = world->w.lastErrorText; delete world; return nullptr; }
+	if (desc)
+	{
+		if (desc->reserveBodies) world->w.bodies.reserve(desc->reserveBodies);
+		if (desc->reserveColliders) world->w.colliders.reserve(desc->reserveColliders);
+		if (desc->reservePairs) ensurePairBuffers(world->w, desc->reservePairs);
+	}
+	return world;
+}
+void mi_world_destroy(mi_world* world) { delete world; }
+const char* mi_last_error(mi_world* world) { return world ? world->w.lastErrorText.c_str() : g_createError.c_str(); }
+
+uint32_t mi_add_body(mi_world* world, int kinematic, float gravityFactor, float linearDamping, float angularDamping, const float pos[3], const float rot[4])
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	World::HBody b{};
+	memcpy(b.pos, pos, 12); memcpy(b.rot, rot, 16);
+	if (kinematic) { b.invMass = 0.f; }                                   // rigid_body.cpp:8-17
+	else { b.invMass = 1.f; b.invInertia[0] = b.invInertia[4] = b.invInertia[8] = 1.f; }
+	b.gravityFactor = gravityFactor; b.linDamp = linearDamping; b.angDamp = angularDamping;
+	W->bodies.push_back(b);
+	W->topologyDirty = true;
+	return (uint32_t)W->bodies.size() - 1;
+}
+
+static uint32_t addCollider(World* w, uint32_t body, uint32_t type, const float* shape, const mi_material* material, const float* pos, const float* rot)
+{
+	if (type != MI_SPHERE && type != MI_CAPSULE && type != MI_AABB && type != MI_OBB) { w->fail(MI_ERR_UNSUPPORTED, "collider type not supported by the HIP narrowphase (cylinder/hull)"); return 0xFFFFFFFFu; }
+	if (body != MI_STATIC_BODY && body >= w->bodies.size()) { w->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_collider: body out of range"); return 0xFFFFFFFFu; }
+	World::HCollider c; memset(&c, 0, sizeof(c));
+	u32 n = (type == MI_SPHERE) ? 4 : (type == MI_CAPSULE ? 7 : (type == MI_AABB ? 6 : 10));
+	memcpy(c.shape, shape, n * sizeof(float));
+	c.restitution = material->restitution; c.friction = material->friction; c.density = material->density;
+	c.type = type; c.body = body;
+	if (pos) memcpy(c.spos, pos, 12);
+	if (rot) memcpy(c.srot, rot, 16); else c.srot[3] = 1.f;
+	u32 id = (u32)w->colliders.size();
+	w->colliders.push_back(c);
+	if (body != MI_STATIC_BODY)
+	{
+		if (w->stateOnDevice) w->downloadState();
+		w->bodies[body].colliders.push_back(id);
+		recalculateProperties(*w, w->bodies[body]);                      // scene.h:60-63
+	}
+	w->topologyDirty = true;
+	return id;
+}
+uint32_t mi_add_collider(mi_world* world, uint32_t body, uint32_t type, const float* shape, const mi_material* material)
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	return addCollider(W, body, type, shape, material, nullptr, nullptr);
+}
+uint32_t mi_add_static_collider(mi_world* world, uint32_t type, const float* shape, const mi_material* material, const float pos[3], const float rot[4])
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	return addCollider(W, MI_STATIC_BODY, type, shape, material, pos, rot);
+}
+
+// ---- constraints (physics.cpp:128-333) ----
+struct Trs { Q4 q; V3 p; };
+static bool bodyTrs(World* w, u32 i, Trs& t)
+{
+	if (i >= w->bodies.size()) { w->fail(MI_ERR_INVALID_ARGUMENT, "constraint: body out of range"); return false; }
+	if (w->stateOnDevice) w->downloadState();
+	const World::HBody& b = w->bodies[i];
+	t.q = q4(b.rot[0], b.rot[1], b.rot[2], b.rot[3]); t.p = v3(b.pos[0], b.pos[1], b.pos[2]);
+	return true;
+}
+static V3 invPos(const Trs& t, V3 p) { return conjugate(t.q) * (p - t.p); }   // inverseTransformPosition, math.cpp:528 (scale 1)
+static V3 invDir(const Trs& t, V3 d) { return conjugate(t.q) * d; }           // inverseTransformDirection, math.cpp:533
+static V3 hv3(const float* p) { return v3(p[0], p[1], p[2]); }
+static void put3(float* o, V3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+
+static uint32_t pushJoint(World* w, u32 type, u32 a, u32 b, const void* pod)
+{
+	JointSet& js = w->joints[type];
+	u32 sz = MI_JOINT_POD_SIZE[type];
+	js.pods.insert(js.pods.end(), (const uint8_t*)pod, (const uint8_t*)pod + sz);
+	js.a.push_back(a); js.b.push_back(b); js.alive.push_back(1);
+	w->jointsDirty = true;
+	return js.count() - 1;
+}
+
+uint32_t mi_add_distance_constraint_local(mi_world* world, uint32_t a, uint32_t b, const float la[3], const float lb[3], float distance)
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	mi_distance_constraint c; memcpy(c.localAnchorA, la, 12); memcpy(c.localAnchorB, lb, 12); c.globalLength = distance;
+	return pushJoint(W, MI_CONSTRAINT_DISTANCE, a, b, &c);
+}
+uint32_t mi_add_distance_constraint_global(mi_world* world, uint32_t a, uint32_t b, const float ga[3], const float gb[3])
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	Trs tA, tB; if (!bodyTrs(W, a, tA) || !bodyTrs(W, b, tB)) return 0xFFFFFFFFu;
+	mi_distance_constraint c; put3(c.localAnchorA, invPos(tA, hv3(ga))); put3(c.localAnchorB, invPos(tB, hv3(gb))); c.globalLength = length(hv3(ga) - hv3(gb));
+	return pushJoint(W, MI_CONSTRAINT_DISTANCE, a, b, &c);
+}
+uint32_t mi_add_ball_constraint_local(mi_world* world, uint32_t a, uint32_t b, const float la[3], const float lb[3])
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	mi_ball_constraint c; memcpy(c.localAnchorA, la, 12); memcpy(c.localAnchorB, lb, 12);
+	return pushJoint(W, MI_CONSTRAINT_BALL, a, b, &c);
+}
+uint32_t mi_add_ball_constraint_global(mi_world* world, uint32_t a, uint32_t b, const float g[3])
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	Trs tA, tB; if (!bodyTrs(W, a, tA) || !bodyTrs(W, b, tB)) return 0xFFFFFFFFu;
+	mi_ball_constraint c; put3(c.localAnchorA, invPos(tA, hv3(g))); put3(c.localAnchorB, invPos(tB, hv3(g)));
+	return pushJoint(W, MI_CONSTRAINT_BALL, a, b, &c);
+}
+uint32_t mi_add_fixed_constraint_global(mi_world* world, uint32_t a, uint32_t b, const float g[3])
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	Trs tA, tB; if (!bodyTrs(W, a, tA) || !bodyTrs(W, b, tB)) return 0xFFFFFFFFu;
+	mi_fixed_constraint c; put3(c.localAnchorA, invPos(tA, hv3(g))); put3(c.localAnchorB, invPos(tB, hv3(g)));
+	Q4 d = conjugate(tB.q) * tA.q;
+	c.initialInvRotationDifference[0] = d.x; c.initialInvRotationDifference[1] = d.y; c.initialInvRotationDifference[2] = d.z; c.initialInvRotationDifference[3] = d.w;
+	return pushJoint(W, MI_CONSTRAINT_FIXED, a, b, &c);
+}
+uint32_t mi_add_hinge_constraint_global(mi_world* world, uint32_t a, uint32_t b, const float anchor[3], const float axis[3], float minLimit, float maxLimit)
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	Trs tA, tB; if (!bodyTrs(W, a, tA) || !bodyTrs(W, b, tB)) return 0xFFFFFFFFu;
+	mi_hinge_constraint c; memset(&c, 0, sizeof(c));
+	put3(c.localAnchorA, invPos(tA, hv3(anchor))); put3(c.localAnchorB, invPos(tB, hv3(anchor)));
+	V3 axA = invDir(tA, hv3(axis));
+	put3(c.localHingeAxisA, axA); put3(c.localHingeAxisB, invDir(tB, hv3(axis)));
+	V3 tan = getTangent(axA), bit = cross(axA, tan);
+	put3(c.localHingeTangentA, tan); put3(c.localHingeBitangentA, bit);
+	put3(c.localHingeTangentB, conjugate(tB.q) * (tA.q * tan));
+	c.minRotationLimit = minLimit; c.maxRotationLimit = maxLimit;
+	c.motorType = MI_MOTOR_VELOCITY; c.motorVelocity = 0.f; c.maxMotorTorque = -1.f;
+	return pushJoint(W, MI_CONSTRAINT_HINGE, a, b, &c);
+}
+uint32_t mi_add_cone_twist_constraint_global(mi_world* world, uint32_t a, uint32_t b, const float anchor[3], const float axis[3], float swingLimit, float twistLimit)
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	Trs tA, tB; if (!bodyTrs(W, a, tA) || !bodyTrs(W, b, tB)) return 0xFFFFFFFFu;
+	mi_cone_twist_constraint c; memset(&c, 0, sizeof(c));
+	put3(c.localAnchorA, invPos(tA, hv3(anchor))); put3(c.localAnchorB, invPos(tB, hv3(anchor)));
+	c.swingLimit = swingLimit; c.twistLimit = twistLimit;
+	V3 axA = invDir(tA, hv3(axis));
+	put3(c.localLimitAxisA, axA); put3(c.localLimitAxisB, invDir(tB, hv3(axis)));
+	V3 tan = getTangent(axA), bit = cross(axA, tan);
+	put3(c.localLimitTangentA, tan); put3(c.localLimitBitangentA, bit);
+	put3(c.localLimitTangentB, conjugate(tB.q) * (tA.q * tan));
+	c.swingMotorType = MI_MOTOR_VELOCITY; c.maxSwingMotorTorque = -1.f; c.twistMotorType = MI_MOTOR_VELOCITY; c.maxTwistMotorTorque = -1.f;
+	return pushJoint(W, MI_CONSTRAINT_CONE_TWIST, a, b, &c);
+}
+uint32_t mi_add_slider_constraint_global(mi_world* world, uint32_t a, uint32_t b, const float anchor[3], const float axis[3], float minLimit, float maxLimit)
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	Trs tA, tB; if (!bodyTrs(W, a, tA) || !bodyTrs(W, b, tB)) return 0xFFFFFFFFu;
+	mi_slider_constraint c; memset(&c, 0, sizeof(c));
+	put3(c.localAnchorA, invPos(tA, hv3(anchor))); put3(c.localAnchorB, invPos(tB, hv3(anchor)));
+	put3(c.localAxisA, invDir(tA, hv3(axis)));
+	Q4 d = conjugate(tB.q) * tA.q;
+	c.initialInvRotationDifference[0] = d.x; c.initialInvRotationDifference[1] = d.y; c.initialInvRotationDifference[2] = d.z; c.initialInvRotationDifference[3] = d.w;
+	c.negDistanceLimit = minLimit; c.posDistanceLimit = maxLimit;
+	c.motorType = MI_MOTOR_VELOCITY; c.motorVelocity = 0.f; c.maxMotorForce = -1.f;
+	return pushJoint(W, MI_CONSTRAINT_SLIDER, a, b, &c);
+}
+
+int mi_constraint_get(mi_world* world, uint32_t type, uint32_t id, void* pod)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (type >= MI_JOINT_TYPES || id >= W->joints[type].count() || !W->joints[type].alive[id]) return MI_ERR_INVALID_ARGUMENT;
+	memcpy(pod, W->joints[type].pods.data() + (size_t)id * MI_JOINT_POD_SIZE[type], MI_JOINT_POD_SIZE[type]);
+	return MI_OK;
+}
+int mi_constraint_set(mi_world* world, uint32_t type, uint32_t id, const void* pod)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (type >= MI_JOINT_TYPES || id >= W->joints[type].count() || !W->joints[type].alive[id]) return MI_ERR_INVALID_ARGUMENT;
+	memcpy(W->joints[type].pods.data() + (size_t)id * MI_JOINT_POD_SIZE[type], pod, MI_JOINT_POD_SIZE[type]);
+	W->jointsDirty = true;
+	return MI_OK;
+}
+int mi_delete_constraint(mi_world* world, uint32_t type, uint32_t id)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (type >= MI_JOINT_TYPES || id >= W->joints[type].count() || !W->joints[type].alive[id]) return MI_ERR_INVALID_ARGUMENT;
+	W->joints[type].alive[id] = 0; W->jointsDirty = true;
+	return MI_OK;
+}
+int mi_delete_all_constraints(mi_world* world)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	for (auto& js : W->joints) { std::fill(js.alive.begin(), js.alive.end(), 0); js.order.clear(); js.colorStart.clear(); }
+	W->jointsDirty = true;
+	return MI_OK;
+}
+
+int mi_apply_force_torque(mi_world* world, uint32_t body, const float f[3], const float t[3])
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
+	if (W->stateOnDevice && !W->topologyDirty && body < W->nb)
+	{
+		float4 cur[2];
+		MI_CHECK(hipMemcpyAsync(cur, W->force.p + 2 * body, sizeof(cur), hipMemcpyDeviceToHost, W->stream)); MI_CHECK(hipStreamSynchronize(W->stream));
+		cur[0].x += f[0]; cur[0].y += f[1]; cur[0].z += f[2]; cur[1].x += t[0]; cur[1].y += t[1]; cur[1].z += t[2];
+		MI_CHECK(hipMemcpyAsync(W->force.p + 2 * body, cur, sizeof(cur), hipMemcpyHostToDevice, W->stream)); MI_CHECK(hipStreamSynchronize(W->stream));
+	}
+	else { World::HBody& b = W->bodies[body]; for (int i = 0; i < 3; ++i) { b.force[i] += f[i]; b.torque[i] += t[i]; } }
+	return W->lastError;
+}
+int mi_set_velocity(mi_world* world, uint32_t body, const float lin[3], const float ang[3])
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
+	World::HBody& b = W->bodies[body];
+	if (W->stateOnDevice && !W->topologyDirty && body < W->nb)
+	{
+		float4 v[2] = { make_float4(lin[0], lin[1], lin[2], b.invMass), make_float4(ang[0], ang[1], ang[2], 0.f) };
+		MI_CHECK(hipMemcpyAsync(W->vel.p + 2 * body, v, sizeof(v), hipMemcpyHostToDevice, W->stream)); MI_CHECK(hipStreamSynchronize(W->stream));
+	}
+	memcpy(b.v, lin, 12); memcpy(b.w, ang, 12);
+	return W->lastError;
+}
+int mi_set_transform(mi_world* world, uint32_t body, const float pos[3], const float rot[4])
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
+	if (W->stateOnDevice && !W->topologyDirty && body < W->nb)
+	{
+		float4 p[2] = { make_float4(pos[0], pos[1], pos[2], 0.f), make_float4(rot[0], rot[1], rot[2], rot[3]) };
+		MI_CHECK(hipMemcpyAsync(W->pose.p + 2 * body, p, sizeof(p), hipMemcpyHostToDevice, W->stream));
+		MI_CHECK(hipMemcpyAsync(W->pose0.p + 2 * body, p, sizeof(p), hipMemcpyHostToDevice, W->stream));
+		MI_CHECK(hipMemcpyAsync(W->poseLerp.p + 2 * body, p, sizeof(p), hipMemcpyHostToDevice, W->stream)); MI_CHECK(hipStreamSynchronize(W->stream));
+	}
+	memcpy(W->bodies[body].pos, pos, 12); memcpy(W->bodies[body].rot, rot, 16);
+	return W->lastError;
+}
+
+int mi_step(mi_world* world, float* timer, const mi_physics_settings* settings, float dt)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (!timer || !settings) return MI_ERR_INVALID_ARGUMENT;
+	return W->step(timer, settings, dt);
+}
+int mi_step_internal(mi_world* world, float dt, uint32_t iterations)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	int e = W->stepInternal(dt, iterations);
+	if (!e && W->nb) MI_CHECK(hipMemcpyAsync(W->poseLerp.p, W->pose.p, sizeof(float4) * 2 * W->nb, hipMemcpyDeviceToDevice, W->stream));
+	return e ? e : W->lastError;
+}
+int mi_synchronize(mi_world* world) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); MI_CHECK(hipStreamSynchronize(W->stream)); return W->lastError; }
+
+int mi_read_transforms(mi_world* world, uint32_t which, float* out7, uint32_t n)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->upload();
+	n = std::min<u32>(n, W->nb);
+	if (!n) return W->lastError;
+	std::vector<float4> h(2 * (size_t)n);
+	const float4* src = which == 0 ? W->poseLerp.p : (which == 1 ? W->pose.p : W->pose0.p);
+	MI_CHECK(hipMemcpyAsync(h.data(), src, sizeof(float4) * h.size(), hipMemcpyDeviceToHost, W->stream)); MI_CHECK(hipStreamSynchronize(W->stream));
+	for (u32 i = 0; i < n; ++i)
+	{
+		float* o = out7 + 7 * (size_t)i;
+		o[0] = h[2 * i].x; o[1] = h[2 * i].y; o[2] = h[2 * i].z; o[3] = h[2 * i + 1].x; o[4] = h[2 * i + 1].y; o[5] = h[2 * i + 1].z; o[6] = h[2 * i + 1].w;
+	}
+	return W->lastError;
+}
+int mi_read_velocities(mi_world* world, float* out6, uint32_t n)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->upload();
+	n = std::min<u32>(n, W->nb);
+	if (!n) return W->lastError;
+	std::vector<float4> h(2 * (size_t)n);
+	MI_CHECK(hipMemcpyAsync(h.data(), W->vel.p, sizeof(float4) * h.size(), hipMemcpyDeviceToHost, W->stream)); MI_CHECK(hipStreamSynchronize(W->stream));
+	for (u32 i = 0; i < n; ++i)
+	{
+		float* o = out6 + 6 * (size_t)i;
+		o[0] = h[2 * i].x; o[1] = h[2 * i].y; o[2] = h[2 * i].z; o[3] = h[2 * i + 1].x; o[4] = h[2 * i + 1].y; o[5] = h[2 * i + 1].z;
+	}
+	return W->lastError;
+}
+int mi_read_mass_properties(mi_world* world, float* out13, uint32_t n)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	n = std::min<u32>(n, (u32)W->bodies.size());
+	for (u32 i = 0; i < n; ++i)
+	{
+		const World::HBody& b = W->bodies[i]; float* o = out13 + 13 * (size_t)i;
+		memcpy(o, b.localCOG, 12); o[3] = b.invMass; memcpy(o + 4, b.invInertia, 36);
+	}
+	return MI_OK;
+}
+int mi_get_stats(mi_world* world, mi_stats* out) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); *out = W->stats; out->numContacts = 0; return MI_OK; }
+int mi_enable_stage_timing(mi_world* world, int enable) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); W->timeStages = enable != 0; return MI_OK; }
+uint32_t mi_num_bodies(mi_world* world) { CHECK_WORLD(0); return (u32)W->bodies.size(); }
+uint32_t mi_num_colliders(mi_world* world) { CHECK_WORLD(0); return (u32)W->colliders.size(); }
+
+int mi_device_pointers(mi_world* world, void** pose, void** vel, void** stream)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->upload();
+	if (pose) *pose = W->pose.p; if (vel) *vel = W->vel.p; if (stream) *stream = (void*)W->stream;
+	return W->lastError;
+}
+
+// ---- inspection ----
+static void d2h(World* w, void* dst, const void* src, size_t bytes)
+{
+	if (!bytes) return;
+	MI_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, w->stream)); MI_CHECK(hipStreamSynchronize(w->stream));
+}
+uint32_t mi_debug_num_pairs(mi_world* world) { CHECK_WORLD(0); return W->hCounters->numPairs; }
+int mi_debug_read_pairs(mi_world* world, uint32_t* out) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); d2h(W, out, W->pairs.p, sizeof(uint2) * W->hCounters->numPairs); return W->lastError; }
+int mi_debug_read_world_colliders(mi_world* world, void* outColliders64, float* outAabbs6)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	u32 n = W->nc;
+	std::vector<ColliderRec> c(n); std::vector<float4> mn(n), mx(n);
+	d2h(W, c.data(), W->colWorld.p, sizeof(ColliderRec) * n); d2h(W, mn.data(), W->aabbMin.p, sizeof(float4) * n); d2h(W, mx.data(), W->aabbMax.p, sizeof(float4) * n);
+	struct Out { float shape[10]; float restitution, friction, density; u32 type, objectType, objectIndex; };
+	Out* o = (Out*)outColliders64;
+	for (u32 i = 0; i < n; ++i)
+	{
+		const float* f = (const float*)&c[i];
+		memcpy(o[i].shape, f, 40); o[i].restitution = f[10]; o[i].friction = f[11]; o[i].density = f[14];
+		o[i].type = mi_f2u(f[12]); o[i].objectIndex = mi_f2u(f[13]); o[i].objectType = (o[i].objectIndex < W->nb) ? 0u : 1u;
+		float* a = outAabbs6 + 6 * (size_t)i;
+		a[0] = mn[i].x; a[1] = mn[i].y; a[2] = mn[i].z; a[3] = mx[i].x; a[4] = mx[i].y; a[5] = mx[i].z;
+	}
+	return W->lastError;
+}
+uint32_t mi_debug_num_manifold_slots(mi_world* world) { CHECK_WORLD(0); return W->hCounters->numPairs ? W->hCounters->numValidPairs : 0; }
+int mi_debug_read_manifolds(mi_world* world, uint32_t* outPairs2, uint32_t* outCounts, void* outContacts4x32, uint32_t* outBodyPairs2)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	u32 n = mi_debug_num_manifold_slots(world);
+	if (!n) return MI_OK;
+	std::vector<ManifoldRec> m(n); std::vector<u64> packed(n);
+	d2h(W, m.data(), W->manifolds.p, sizeof(ManifoldRec) * n); d2h(W, packed.data(), W->pairsSorted.p, sizeof(u64) * n);
+	struct Contact { float point[3], depth, normal[3]; u32 fr; };
+	Contact* oc = (Contact*)outContacts4x32;
+	for (u32 i = 0; i < n; ++i)
+	{
+		outPairs2[2 * i] = (u32)packed[i]; outPairs2[2 * i + 1] = (u32)(packed[i] >> 32);
+		outCounts[i] = m[i].ids.z; outBodyPairs2[2 * i] = m[i].ids.x; outBodyPairs2[2 * i + 1] = m[i].ids.y;
+		for (u32 k = 0; k < 4; ++k)
+		{
+			Contact& c = oc[4 * (size_t)i + k];
+			c.point[0] = m[i].p[k].x; c.point[1] = m[i].p[k].y; c.point[2] = m[i].p[k].z; c.depth = m[i].p[k].w;
+			c.normal[0] = m[i].nf.x; c.normal[1] = m[i].nf.y; c.normal[2] = m[i].nf.z; c.fr = mi_f2u(m[i].nf.w);
+		}
+	}
+	return W->lastError;
+}
+uint32_t mi_debug_num_colors(mi_world* world) { CHECK_WORLD(0); return MI_MAX_COLORS + 1; }
+int mi_debug_read_schedule(mi_world* world, uint32_t* outManifoldSlots, uint32_t* outColorStart)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	u32 n = W->hCounters->numPairs ? W->hCounters->numManifolds : 0;
+	d2h(W, outManifoldSlots, W->mOrder.p, sizeof(u32) * n);
+	memcpy(outColorStart, W->hCounters->colorStart, sizeof(u32) * (MI_MAX_COLORS + 2));
+	return W->lastError;
+}
+int mi_debug_read_joint_order(mi_world* world, uint32_t type, uint32_t* out)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (type >= MI_JOINT_TYPES) return MI_ERR_INVALID_ARGUMENT;
+	W->uploadJoints();
+	memcpy(out, W->joints[type].order.data(), sizeof(u32) * W->joints[type].order.size());
+	return MI_OK;
+}
+int mi_debug_read_body_state(mi_world* world, float* outCog4, float* outInvInertia12, uint32_t n)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	n = std::min<u32>(n, W->nb + 1);
+	d2h(W, outCog4, W->cog.p, sizeof(float4) * n); d2h(W, outInvInertia12, W->invIw.p, sizeof(float4) * 3 * n);
+	return W->lastError;
+}
+
+} // extern "C"

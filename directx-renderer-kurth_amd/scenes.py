@@ -1,0 +1,283 @@
+"""Synthetic scene generators for the BASELINE.json configs.
+
+A `Scene` is a backend-neutral description (bodies, colliders, joints) that `instantiate()` replays through the
+add API of any world object exposing the reference's call shapes (add_body / add_collider / add_*_constraint_global):
+the HIP world (`World` in this package) in production and bench, the CPU oracle in tests.
+
+Randomness is xorshift64 exactly as the reference's `random_number_generator` (src/core/random.h:14-60), seeds as
+listed in BASELINE.md.  The humanoid ragdoll geometry restates src/physics/ragdoll.cpp:10-123 (input data only).
+"""
+import math
+import numpy as np
+
+SPHERE, CAPSULE, CYLINDER, AABB, OBB = 0, 1, 2, 3, 4
+STATIC = 0xFFFFFFFF
+_M64 = (1 << 64) - 1
+
+
+class XorShift64:
+    """src/core/random.h:14-60."""
+
+    def __init__(self, seed):
+        self.state = seed & _M64
+
+    def u64(self):
+        x = self.state
+        x ^= (x << 13) & _M64
+        x ^= x >> 7
+        x ^= (x << 17) & _M64
+        self.state = x
+        return x
+
+    def f01(self):
+        return np.float32(self.u64() & 0xFFFFFFFF) / np.float32(0xFFFFFFFF)
+
+    def between(self, lo, hi):
+        return float(np.float32(lo) + self.f01() * (np.float32(hi) - np.float32(lo)))
+
+    def unit_quat(self):
+        # uniform-ish random rotation: normalised 4-vector in [-1,1]^4, rejecting the corners
+        while True:
+            q = np.array([self.between(-1, 1) for _ in range(4)], np.float64)
+            n = float(np.dot(q, q))
+            if 1e-4 < n <= 1.0:
+                q = (q / math.sqrt(n)).astype(np.float32)
+                return q / np.float32(np.sqrt(np.dot(q, q)))
+
+
+class Scene:
+    def __init__(self, name, dt=1.0 / 120.0):
+        self.name = name
+        self.dt = dt
+        self.bodies = []      # (pos3, rot4, kinematic, gravityFactor, linDamp, angDamp)
+        self.colliders = []   # (body or STATIC, type, shape[<=10], material3, static_pos3, static_rot4)
+        self.joints = []      # ("hinge"|"cone_twist"|..., a, b, args...)
+
+    def add_body(self, pos, rot=(0, 0, 0, 1), kinematic=False, gravity_factor=1.0, linear_damping=0.4, angular_damping=0.4):
+        self.bodies.append((tuple(float(x) for x in pos), tuple(float(x) for x in rot), kinematic, gravity_factor, linear_damping, angular_damping))
+        return len(self.bodies) - 1
+
+    def add_collider(self, body, ctype, shape, material, pos=(0, 0, 0), rot=(0, 0, 0, 1)):
+        self.colliders.append((body, ctype, tuple(float(x) for x in shape), tuple(material), tuple(pos), tuple(rot)))
+        return len(self.colliders) - 1
+
+    def add_joint(self, kind, a, b, *args):
+        self.joints.append((kind, a, b) + args)
+
+    @property
+    def num_bodies(self):
+        return len(self.bodies)
+
+    def instantiate(self, world):
+        for pos, rot, kin, g, ld, ad in self.bodies:
+            world.add_body(pos, rot, kinematic=kin, gravity_factor=g, linear_damping=ld, angular_damping=ad)
+        for body, ctype, shape, mat, pos, rot in self.colliders:
+            if body == STATIC:
+                world.add_static_collider(ctype, shape, mat, pos, rot)
+            else:
+                world.add_collider(body, ctype, shape, mat)
+        for j in self.joints:
+            kind, a, b, args = j[0], j[1], j[2], j[3:]
+            getattr(world, "add_%s_constraint_global" % kind)(a, b, *args)
+        return world
+
+
+DEFAULT_MATERIAL = (0.1, 0.5, 1.0)  # restitution, friction, density (reference application.cpp:176)
+
+
+def _ground(scene, half_xz, material=DEFAULT_MATERIAL):
+    # the reference's "platform": static AABB centre (0,-4,0) (application.cpp:209-212), widened to the scene
+    scene.add_collider(STATIC, AABB, (-half_xz, -8.0, -half_xz, half_xz, 0.0, half_xz), material)
+
+
+def c1_boxes(n=64, seed=15681923):
+    """C1: n OBBs, half-extents (0.5,0.5,0.5)-(1,1,2), random orientation, dropped from y in [2,20] over 8x8 m."""
+    rng = XorShift64(seed)
+    s = Scene("c1_boxes_%d" % n)
+    _ground(s, 30.0)
+    for _ in range(n):
+        he = (rng.between(0.5, 1.0), rng.between(0.5, 1.0), rng.between(0.5, 2.0))
+        pos = (rng.between(-4, 4), rng.between(2, 20), rng.between(-4, 4))
+        rot = rng.unit_quat()
+        b = s.add_body(pos, rot)
+        s.add_collider(b, OBB, (0, 0, 0, 1, 0, 0, 0) + he, DEFAULT_MATERIAL)
+    return s
+
+
+def c2_spheres(nx=22, ny=21, nz=22, seed=519431, radius=0.5, jitter=1e-3):
+    """C2: nx*ny*nz unit-density spheres r=0.5 in a lattice with +-1 mm jitter (tie-free SAP), resting on the ground."""
+    rng = XorShift64(seed)
+    s = Scene("c2_spheres_%d" % (nx * ny * nz))
+    _ground(s, max(nx, nz) * radius * 2 + 20.0)
+    d = 2.0 * radius
+    for iy in range(ny):
+        for iz in range(nz):
+            for ix in range(nx):
+                pos = ((ix - 0.5 * (nx - 1)) * d + rng.between(-jitter, jitter),
+                       radius + iy * d + rng.between(0, jitter),
+                       (iz - 0.5 * (nz - 1)) * d + rng.between(-jitter, jitter))
+                b = s.add_body(pos)
+                s.add_collider(b, SPHERE, (0, 0, 0, radius), DEFAULT_MATERIAL)
+    return s
+
+
+def c3_mixed(n=100000, seed=14878213, area=200.0, column_height=50):
+    """C3/C5: n bodies, 1:1:1 sphere r in [0.3,0.6] / capsule (half-height 0.5, r 0.25) / OBB he in [0.3,0.8],
+    random orientations, poured as `column_height`-high columns on an area x area m ground."""
+    rng = XorShift64(seed)
+    s = Scene("c3_mixed_%d" % n)
+    _ground(s, area * 0.5 + 10.0)
+    ncol = (n + column_height - 1) // column_height
+    side = int(math.ceil(math.sqrt(ncol)))
+    pitch = area / side
+    i = 0
+    for c in range(ncol):
+        cx = (c % side - 0.5 * (side - 1)) * pitch
+        cz = (c // side - 0.5 * (side - 1)) * pitch
+        for k in range(column_height):
+            if i >= n:
+                break
+            pos = (cx + rng.between(-0.3, 0.3), 1.0 + 1.7 * k + rng.between(0, 0.1), cz + rng.between(-0.3, 0.3))
+            rot = rng.unit_quat()
+            b = s.add_body(pos, rot)
+            kind = i % 3
+            if kind == 0:
+                s.add_collider(b, SPHERE, (0, 0, 0, rng.between(0.3, 0.6)), DEFAULT_MATERIAL)
+            elif kind == 1:
+                s.add_collider(b, CAPSULE, (0, -0.5, 0, 0, 0.5, 0, 0.25), DEFAULT_MATERIAL)
+            else:
+                he = (rng.between(0.3, 0.8), rng.between(0.3, 0.8), rng.between(0.3, 0.8))
+                s.add_collider(b, OBB, (0, 0, 0, 1, 0, 0, 0) + he, DEFAULT_MATERIAL)
+            i += 1
+    return s
+
+
+# ---- humanoid ragdoll (reference src/physics/ragdoll.cpp:10-123) ------------------------------------------
+def _quat_axis_angle(axis, angle):
+    h = np.float32(angle) * np.float32(0.5)
+    s = np.float32(math.sin(h))
+    return (float(axis[0] * s), float(axis[1] * s), float(axis[2] * s), float(np.float32(math.cos(h))))
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return (aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+            aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz)
+
+
+def _qrot(q, v):
+    p = (v[0], v[1], v[2], 0.0)
+    c = (-q[0], -q[1], -q[2], q[3])
+    r = _qmul(_qmul(q, p), c)
+    return (r[0], r[1], r[2])
+
+
+def add_ragdoll(s, hip, yaw=0.0):
+    """Appends one 14-body humanoid (17 colliders, 7 cone-twist + 6 hinge).  Returns the body ids."""
+    sc = 0.42
+    mat = (0.2, 1.0, 985.0)
+    d2r = math.pi / 180.0
+    Z = (0.0, 0.0, 1.0)
+    ident = (0.0, 0.0, 0.0, 1.0)
+    parts = {  # name: (position * scale, rotation)                                    ragdoll.cpp:21-34
+        "torso": ((0.0, 0.0, 0.0), ident), "head": ((0.0, 1.45, 0.0), ident),
+        "lua": ((-0.6, 0.75, 0.0), _quat_axis_angle(Z, -30 * d2r)), "lla": ((-0.884, 0.044, -0.043), _quat_axis_angle(Z, -20 * d2r)),
+        "rua": ((0.6, 0.75, 0.0), _quat_axis_angle(Z, 30 * d2r)), "rla": ((0.884, 0.044, -0.043), _quat_axis_angle(Z, 20 * d2r)),
+        "lul": ((-0.371, -0.812, 0.0), _quat_axis_angle(Z, -10 * d2r)), "lll": ((-0.452, -1.955, 0.0), _quat_axis_angle(Z, -3.5 * d2r)),
+        "lf": ((-0.498, -2.585, -0.18), ident), "lt": ((-0.498, -2.585, -0.637), ident),
+        "rul": ((0.371, -0.812, 0.0), _quat_axis_angle(Z, 10 * d2r)), "rll": ((0.452, -1.955, 0.0), _quat_axis_angle(Z, 3.5 * d2r)),
+        "rf": ((0.498, -2.585, -0.18), ident), "rt": ((0.498, -2.585, -0.637), ident),
+    }
+    order = ["torso", "head", "lua", "lla", "rua", "rla", "lul", "lll", "lf", "lt", "rul", "rll", "rf", "rt"]
+    T = {k: (tuple(sc * x for x in p), q) for k, (p, q) in parts.items()}
+    yawq = _quat_axis_angle((0.0, 1.0, 0.0), yaw)
+
+    def world_tf(name):  # ragdoll.cpp:125-133: rotate about the hip, then translate
+        p, q = T[name]
+        wp = _qrot(yawq, p)
+        return (wp[0] + hip[0], wp[1] + hip[1], wp[2] + hip[2]), _qmul(yawq, q)
+
+    ids = {}
+    for name in order:
+        pos, rot = world_tf(name)
+        ids[name] = s.add_body(pos, rot)
+
+    def cap(name, a, b, r):
+        s.add_collider(ids[name], CAPSULE, tuple(sc * x for x in a) + tuple(sc * x for x in b) + (sc * r,), mat)
+
+    cap("torso", (-0.2, 0, 0), (0.2, 0, 0), 0.25); cap("torso", (-0.16, 0.32, 0), (0.16, 0.32, 0), 0.2)       # ragdoll.cpp:36-42
+    cap("torso", (-0.14, 0.62, 0), (0.14, 0.62, 0), 0.22); cap("torso", (-0.14, 0.92, 0), (0.14, 0.92, 0), 0.2)
+    cap("head", (0, -0.075, 0), (0, 0.075, 0), 0.25)
+    for n in ("lua", "lla", "rua", "rla"):
+        cap(n, (0, -0.2, 0), (0, 0.2, 0), 0.15)
+    cap("lul", (0, -0.3, 0), (0, 0.3, 0), 0.25); cap("lll", (0, -0.3, 0), (0, 0.3, 0), 0.18)
+    foot = tuple(sc * x for x in (0.1587, 0.1, 0.3424))
+    s.add_collider(ids["lf"], AABB, tuple(-x for x in foot) + foot, mat)
+    cap("lt", (-0.0587, 0, 0), (0.0587, 0, 0), 0.1)
+    cap("rul", (0, -0.3, 0), (0, 0.3, 0), 0.25); cap("rll", (0, -0.3, 0), (0, 0.3, 0), 0.18)
+    s.add_collider(ids["rf"], AABB, tuple(-x for x in foot) + foot, mat)
+    cap("rt", (-0.0587, 0, 0), (0.0587, 0, 0), 0.1)
+
+    def tp(name, local):  # transformPosition(partTransform, scale*local) in the ragdoll's frame, then placed
+        p, q = T[name]
+        r = _qrot(q, tuple(sc * x for x in local))
+        lp = (r[0] + p[0], r[1] + p[1], r[2] + p[2])
+        wp = _qrot(yawq, lp)
+        return (wp[0] + hip[0], wp[1] + hip[1], wp[2] + hip[2])
+
+    def td(name, d):
+        return _qrot(yawq, _qrot(T[name][1], d))
+
+    def wd(d):
+        return _qrot(yawq, d)
+
+    n2 = 1.0 / math.sqrt(2.0)
+    # NB: the reference creates joints before applying initialRotation; with local anchors that is equivalent to
+    # creating them in the rotated pose, which is what we do (global anchors/axes rotated by yaw).          ragdoll.cpp:108-123
+    s.add_joint("cone_twist", ids["torso"], ids["head"], tp("torso", (0, 1.2, 0)), wd((0, 1, 0)), 50 * d2r, 90 * d2r)
+    s.add_joint("cone_twist", ids["torso"], ids["lua"], tp("torso", (-0.4, 1.0, 0)), wd((-1, 0, 0)), 130 * d2r, 90 * d2r)
+    s.add_joint("hinge", ids["lua"], ids["lla"], tp("lua", (0, -0.42, 0)), wd((n2, 0, n2)), -5 * d2r, 85 * d2r)
+    s.add_joint("cone_twist", ids["torso"], ids["rua"], tp("torso", (0.4, 1.0, 0)), wd((1, 0, 0)), 130 * d2r, 90 * d2r)
+    s.add_joint("hinge", ids["rua"], ids["rla"], tp("rua", (0, -0.42, 0)), wd((n2, 0, -n2)), -5 * d2r, 85 * d2r)
+    s.add_joint("cone_twist", ids["torso"], ids["lul"], tp("torso", (-0.3, -0.25, 0)), td("lul", (0, -1, 0)), -1.0, 30 * d2r)
+    s.add_joint("hinge", ids["lul"], ids["lll"], tp("lul", (0, -0.6, 0)), wd((1, 0, 0)), -90 * d2r, 5 * d2r)
+    s.add_joint("cone_twist", ids["lll"], ids["lf"], tp("lll", (0, -0.52, 0)), td("lll", (0, -1, 0)), 75 * d2r, 20 * d2r)
+    s.add_joint("hinge", ids["lf"], ids["lt"], tp("lf", (0, 0, -0.36)), wd((1, 0, 0)), -45 * d2r, 45 * d2r)
+    s.add_joint("cone_twist", ids["torso"], ids["rul"], tp("torso", (0.3, -0.25, 0)), td("rul", (0, -1, 0)), -1.0, 30 * d2r)
+    s.add_joint("hinge", ids["rul"], ids["rll"], tp("rul", (0, -0.6, 0)), wd((1, 0, 0)), -90 * d2r, 5 * d2r)
+    s.add_joint("cone_twist", ids["rll"], ids["rf"], tp("rll", (0, -0.52, 0)), td("rll", (0, -1, 0)), 75 * d2r, 20 * d2r)
+    s.add_joint("hinge", ids["rf"], ids["rt"], tp("rf", (0, 0, -0.36)), wd((1, 0, 0)), -45 * d2r, 45 * d2r)
+    return [ids[n] for n in order]
+
+
+def c4_ragdolls(n=256, pitch=3.0, hip_y=1.25):
+    """C4: n humanoid ragdolls on a sqrt(n) x sqrt(n) grid, hips at y=1.25 (learned_locomotion.cpp:446), 60 Hz."""
+    s = Scene("c4_ragdolls_%d" % n, dt=1.0 / 60.0)
+    side = int(math.ceil(math.sqrt(n)))
+    _ground(s, side * pitch * 0.5 + 20.0, material=(0.1, 1.0, 1.0))
+    for i in range(n):
+        x = (i % side - 0.5 * (side - 1)) * pitch
+        z = (i // side - 0.5 * (side - 1)) * pitch
+        add_ragdoll(s, (x, hip_y, z))
+    return s
+
+
+def by_name(name):
+    if name == "c1":
+        return c1_boxes()
+    if name == "c2":
+        return c2_spheres()
+    if name == "c2_small":
+        return c2_spheres(10, 10, 10)
+    if name == "c3":
+        return c3_mixed()
+    if name == "c3_small":
+        return c3_mixed(3000, area=40.0, column_height=30)
+    if name == "c4":
+        return c4_ragdolls()
+    if name == "c4_small":
+        return c4_ragdolls(4)
+    if name == "c5":
+        return c3_mixed(1000000, area=700.0)
+    raise KeyError(name)

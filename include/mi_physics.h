@@ -1,0 +1,147 @@
+/* mi_physics.h — C-ABI of the MI355X-native rigid-body stepper (libmi_physics.so).
+ *
+ * Drop-in boundary for the `src/physics` hot path of study-game-engines/directx-renderer-kurth: every entry point
+ * below names the reference interface it replaces (file:line under /root/reference/src).  Plain pointers and sizes
+ * only; all host pointers are caller-owned and only touched during the call; a world owns its device memory and one
+ * HIP stream; a world is not re-entrant (the reference's physics step is single-threaded per scene).
+ * Every function returning `int` returns MI_OK (0) or an MI_ERR_* code instead of the reference's ASSERT/__debugbreak
+ * (pch.h:33-34); mi_last_error() gives the text.  There is NO CPU fallback: without a usable HIP device
+ * mi_world_create() fails with MI_ERR_NO_DEVICE.
+ *
+ * The existing C-ABI precedent in the reference is the Physics-Lib DLL (learning/learned_locomotion.cpp:395-489,
+ * premake5.lua:388-462): global singletons + caller-owned float buffers; we keep caller-owned buffers and replace
+ * the singletons by an opaque handle.
+ */
+#ifndef MI_PHYSICS_H
+#define MI_PHYSICS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_world mi_world;
+
+enum { MI_OK = 0, MI_ERR_NO_DEVICE = 1, MI_ERR_INVALID_ARGUMENT = 2, MI_ERR_HIP = 3, MI_ERR_CAPACITY = 4, MI_ERR_UNSUPPORTED = 5 };
+
+/* collider_type, physics.h:58-70 — the enum order is load-bearing (pair kernels are bucketed by it). */
+enum { MI_COLLIDER_SPHERE = 0, MI_COLLIDER_CAPSULE = 1, MI_COLLIDER_CYLINDER = 2, MI_COLLIDER_AABB = 3, MI_COLLIDER_OBB = 4, MI_COLLIDER_HULL = 5 };
+/* constraint_type, constraints.h:14-28 */
+enum { MI_CONSTRAINT_DISTANCE = 0, MI_CONSTRAINT_BALL = 1, MI_CONSTRAINT_FIXED = 2, MI_CONSTRAINT_HINGE = 3, MI_CONSTRAINT_CONE_TWIST = 4, MI_CONSTRAINT_SLIDER = 5 };
+/* constraint_motor_type, constraints.h:39-43 */
+enum { MI_MOTOR_VELOCITY = 0, MI_MOTOR_POSITION = 1 };
+
+#define MI_STATIC_BODY 0xFFFFFFFFu
+
+/* physics_material (physics.h:40-47) without the sound-selection tag. */
+typedef struct mi_material { float restitution, friction, density; } mi_material;
+
+/* physics_settings (physics.h:382-397), field for field, minus the two std::function callbacks. */
+typedef struct mi_physics_settings
+{
+	uint32_t fixedFrameRate;               /* bool */
+	uint32_t frameRate;                    /* 120 */
+	uint32_t maxPhysicsIterationsPerFrame; /* 4 */
+	uint32_t numRigidSolverIterations;     /* 30 */
+	uint32_t numClothVelocityIterations, numClothPositionIterations, numClothDriftIterations; /* accepted, unused (cloth is out of scope) */
+	uint32_t simdBroadPhase, simdNarrowPhase, simdConstraintSolver;                           /* accepted, unused: there is one (HIP) path */
+} mi_physics_settings;
+
+typedef struct mi_world_desc
+{
+	int32_t device;            /* HIP device ordinal; -1 = current device */
+	uint32_t reserveBodies;    /* capacity hints, 0 = grow on demand */
+	uint32_t reserveColliders;
+	uint32_t reservePairs;
+} mi_world_desc;
+
+/* Counters of the last internal step — the reference's CPU_PROFILE_STATs (physics.cpp:1258-1262) plus per-stage times. */
+typedef struct mi_stats
+{
+	uint32_t numRigidBodies, numColliders, numBroadphaseOverlaps, numCollisions, numContacts;
+	uint32_t numColors, numJoints, numInternalSteps;
+	float msCollidersBroad, msNarrow, msSolverSetup, msSolve, msIntegrate, msTotal; /* HIP-event times, only when timing is enabled */
+} mi_stats;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------ */
+mi_world* mi_world_create(const mi_world_desc* desc);                 /* replaces game_scene + memory_arena ownership (physics.cpp:1205,1361) */
+void mi_world_destroy(mi_world* w);
+const char* mi_last_error(mi_world* w);                               /* w may be NULL for create-time errors */
+
+/* ---- add API --------------------------------------------------------------------------------------------------- */
+/* entity.addComponent<rigid_body_component>(kinematic, gravityFactor, linearDamping=.4, angularDamping=.4) on an entity with
+ * transform {pos, rot}: rigid_body.h:21, rigid_body.cpp:6-27, scene.h:69-84.  Returns the body index (= add order). */
+uint32_t mi_add_body(mi_world* w, int kinematic, float gravityFactor, float linearDamping, float angularDamping, const float pos[3], const float rot[4]);
+/* entity.addComponent<collider_component>(collider_component::as{Sphere,Capsule,Cylinder,AABB,OBB}(shape, material)): physics.h:110-157,
+ * scene.h:38-63 (recomputes the body's mass properties, rigid_body.cpp:29-81).  shape = up to 10 floats in the parent's local space:
+ * sphere c3,r | capsule/cylinder A3,B3,r | aabb min3,max3 | obb quat4,center3,radius3.  Returns the collider index. */
+uint32_t mi_add_collider(mi_world* w, uint32_t body, uint32_t type, const float* shape, const mi_material* material);
+/* Collider on an entity without a rigid body (static_collider, physics.cpp:667-671); {pos, rot} is that entity's transform. */
+uint32_t mi_add_static_collider(mi_world* w, uint32_t type, const float* shape, const mi_material* material, const float pos[3], const float rot[4]);
+
+/* add{Distance,Ball,Fixed,Hinge,ConeTwist,Slider}ConstraintFrom{Local,Global}Points: physics.h:209-235, physics.cpp:128-333.
+ * Global variants derive the local anchors/axes from the bodies' CURRENT transforms.  Return the per-type constraint id. */
+uint32_t mi_add_distance_constraint_local(mi_world* w, uint32_t a, uint32_t b, const float localAnchorA[3], const float localAnchorB[3], float distance);
+uint32_t mi_add_distance_constraint_global(mi_world* w, uint32_t a, uint32_t b, const float globalAnchorA[3], const float globalAnchorB[3]);
+uint32_t mi_add_ball_constraint_local(mi_world* w, uint32_t a, uint32_t b, const float localAnchorA[3], const float localAnchorB[3]);
+uint32_t mi_add_ball_constraint_global(mi_world* w, uint32_t a, uint32_t b, const float globalAnchor[3]);
+uint32_t mi_add_fixed_constraint_global(mi_world* w, uint32_t a, uint32_t b, const float globalAnchor[3]);
+uint32_t mi_add_hinge_constraint_global(mi_world* w, uint32_t a, uint32_t b, const float globalAnchor[3], const float globalHingeAxis[3], float minLimit, float maxLimit);
+uint32_t mi_add_cone_twist_constraint_global(mi_world* w, uint32_t a, uint32_t b, const float globalAnchor[3], const float globalAxis[3], float swingLimit, float twistLimit);
+uint32_t mi_add_slider_constraint_global(mi_world* w, uint32_t a, uint32_t b, const float globalAnchor[3], const float globalAxis[3], float minLimit, float maxLimit);
+
+/* T& getConstraint(scene, handle) (physics.h:248-253) as get/set of the POD whose layout is byte-identical to the reference's
+ * distance/ball/fixed/hinge/cone_twist/slider_constraint structs (constraints.h:73-80,129-135,175-183,229-257,346-380,497-520;
+ * 28/24/40/104/120/72 bytes).  Motors are driven by writing fields, as learned_locomotion.cpp:73-91 does. */
+int mi_constraint_get(mi_world* w, uint32_t type, uint32_t id, void* pod);
+int mi_constraint_set(mi_world* w, uint32_t type, uint32_t id, const void* pod);
+int mi_delete_constraint(mi_world* w, uint32_t type, uint32_t id);    /* deleteConstraint, physics.h:257-262 */
+int mi_delete_all_constraints(mi_world* w);                           /* deleteAllConstraints, physics.h:255 */
+
+/* rigid_body_component::{forceAccumulator,torqueAccumulator} += (testPhysicsInteraction applies them the same way, physics.cpp:624-628). */
+int mi_apply_force_torque(mi_world* w, uint32_t body, const float force[3], const float torque[3]);
+int mi_set_velocity(mi_world* w, uint32_t body, const float linear[3], const float angular[3]);
+int mi_set_transform(mi_world* w, uint32_t body, const float pos[3], const float rot[4]);
+
+/* ---- per-frame -------------------------------------------------------------------------------------------------- */
+/* void physicsStep(game_scene&, memory_arena&, float& timer, const physics_settings&, float dt): physics.h:405, physics.cpp:1364-1413.
+ * The arena argument has no counterpart (per-step arrays live in device memory owned by the world). */
+int mi_step(mi_world* w, float* timer, const mi_physics_settings* settings, float dt);
+/* One physicsStepInternal (physics.cpp:1180-1362) at exactly dt — what bench.py and the parity tests time and compare. */
+int mi_step_internal(mi_world* w, float dt, uint32_t numRigidSolverIterations);
+int mi_synchronize(mi_world* w);                                       /* waits for the world's stream */
+
+/* ---- results (transform_component / physics_transform1 / rigid_body_component.{v,w} write-back, physics.cpp:1342-1347,1399-1411) */
+/* which: 0 = interpolated transform_component, 1 = physics_transform1, 2 = physics_transform0.  out = n x {pos3, quat4}. */
+int mi_read_transforms(mi_world* w, uint32_t which, float* out7, uint32_t n);
+int mi_read_velocities(mi_world* w, float* out6, uint32_t n);          /* n x {linear3, angular3} */
+int mi_read_mass_properties(mi_world* w, float* out13, uint32_t n);    /* n x {localCOG3, invMass, invInertia9 (column-major)} */
+int mi_get_stats(mi_world* w, mi_stats* out);
+int mi_enable_stage_timing(mi_world* w, int enable);
+uint32_t mi_num_bodies(mi_world* w);
+uint32_t mi_num_colliders(mi_world* w);
+
+/* ---- device-resident access for multi-GPU halo exchange and zero-copy callers ------------------------------------- */
+/* Raw device pointers (valid until the next add call): pose = 2 x float4 per body {pos.xyz,0},{quat}; vel = 2 x float4 per body
+ * {v.xyz, invMass},{w.xyz,0}.  The caller may read/write them on `stream` between steps (ghost-body refresh). */
+int mi_device_pointers(mi_world* w, void** pose, void** vel, void** stream);
+
+/* ---- inspection of the last internal step (parity tests; mirrors the arrays of physics.cpp:1207-1228) ---------------- */
+uint32_t mi_debug_num_pairs(mi_world* w);
+int mi_debug_read_pairs(mi_world* w, uint32_t* outPairs2);                              /* broadphase overlaps, (A,B) collider indices */
+int mi_debug_read_world_colliders(mi_world* w, void* outColliders64, float* outAabbs6); /* worldSpaceColliders / worldSpaceAABBs */
+uint32_t mi_debug_num_manifold_slots(mi_world* w);
+/* Per candidate pair after prune/classify/bucket (collision_narrow.cpp:2346-2453): ordered collider pair, contact count, and up to 4
+ * contacts in the reference's 32-byte collision_contact layout (physics.h:347-354). */
+int mi_debug_read_manifolds(mi_world* w, uint32_t* outPairs2, uint32_t* outCounts, void* outContacts4x32, uint32_t* outBodyPairs2);
+/* Gauss-Seidel schedule of the contact solve: manifold slots in execution order + colour boundaries. */
+uint32_t mi_debug_num_colors(mi_world* w);
+int mi_debug_read_schedule(mi_world* w, uint32_t* outManifoldSlots, uint32_t* outColorStart /* numColors+1 */);
+int mi_debug_read_joint_order(mi_world* w, uint32_t type, uint32_t* outJointIds);
+int mi_debug_read_body_state(mi_world* w, float* outCog4, float* outInvInertia12, uint32_t nPlusOne); /* rbGlobal: {cog.xyz, invMass}, 3 x float4 columns */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,911 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see omath.h header).  PARITY UNPINNED by the reference (it has no tests).
+// World, mass properties, broadphase, narrowphase driver, step and C API of the CPU restatement.
+// Follows src/physics/physics.cpp:631-756 (world-space colliders), :1180-1413 (physicsStepInternal/physicsStep),
+// :1416-1519 (mass properties), rigid_body.cpp:6-142, collision_broad.cpp:87-166 + 297-447,
+// collision_narrow.cpp:2221-2253 + 2328-2603.  Body index = add order; collider index = add order
+// (the reference's EnTT storage order is not observable here, SURVEY §8c "Third-party arithmetic").
+#include "onarrow.h"
+#include "oconstraints.h"
+#include "owide.h"
+#include <vector>
+#include <cstdio>
+
+namespace orc {
+
+u32 g_gjkMaxItersSeen = 0;
+u32 g_epaMaxTriangles = 0, g_epaMaxEdges = 0, g_epaMaxBorder = 0;
+
+static const float GRAVITY = -9.81f; // physics.h:11
+static const u32 STATIC_BODY = 0xFFFFFFFFu;
+
+// rigid_body.h:18-46 + physics_transform0/1 (rigid_body.h:48-58) + the entity's transform_component
+struct body
+{
+	vec3 localCOGPosition; float invMass; mat3 invInertia;
+	float gravityFactor, linearDamping, angularDamping;
+	vec3 linearVelocity, angularVelocity, forceAccumulator, torqueAccumulator;
+	trs transform, transform0, transform1;
+	std::vector<u32> colliders; // add order; the reference's intrusive list walks it newest-first (scene.h:56-58)
+};
+
+struct collider
+{
+	collider_union local;  // shape in the parent's local space
+	u32 parent;            // body id or STATIC_BODY
+	trs staticTransform;   // transform of a static collider's entity
+};
+
+struct sap_endpoint { float value; u32 collider; bool start; };
+
+// physics.h:382-397 minus the std::function callbacks
+struct physics_settings
+{
+	u32 fixedFrameRate, frameRate, maxPhysicsIterationsPerFrame, numRigidSolverIterations;
+	u32 numClothVelocityIterations, numClothPositionIterations, numClothDriftIterations;
+	u32 simdBroadPhase, simdNarrowPhase, simdConstraintSolver;
+};
+
+enum solver_mode : u32 { solver_scalar = 0, solver_wide8 = 1, solver_custom_order = 2 };
+
+struct world
+{
+	std::vector<body> bodies;
+	std::vector<collider> colliders;
+
+	std::vector<distance_constraint> distanceConstraints; std::vector<constraint_body_pair> distancePairs;
+	std::vector<ball_constraint> ballConstraints; std::vector<constraint_body_pair> ballPairs;
+	std::vector<fixed_constraint> fixedConstraints; std::vector<constraint_body_pair> fixedPairs;
+	std::vector<hinge_constraint> hingeConstraints; std::vector<constraint_body_pair> hingePairs;
+	std::vector<cone_twist_constraint> coneTwistConstraints; std::vector<constraint_body_pair> coneTwistPairs;
+	std::vector<slider_constraint> sliderConstraints; std::vector<constraint_body_pair> sliderPairs;
+
+	// sap_context (collision_broad.cpp:20-24)
+	std::vector<sap_endpoint> endpoints;
+	u32 sortingAxis = 0;
+
+	// Per-step arrays kept for inspection by tests.
+	std::vector<bounding_box> worldSpaceAABBs;
+	std::vector<collider_union> worldSpaceColliders;
+	std::vector<collider_pair> broadphasePairs;
+	std::vector<collision_contact> contacts;
+	std::vector<constraint_body_pair> contactBodyPairs;
+	std::vector<collider_pair> collidingPairs;       // ordered (A,B) as the contact normal sees them
+	std::vector<u8> contactCountPerCollision;
+	std::vector<u32> contactCollisionIndex;          // contact -> index into collidingPairs
+	std::vector<rigid_body_global_state> rbGlobal;   // after applyGravityAndIntegrateForces (+ solve)
+	std::vector<rigid_body_global_state> rbGlobalPreSolve;
+	std::vector<collision_constraint> contactConstraints;
+	std::vector<sched_slot> contactSlots;
+	u32 usedSortingAxis = 0;
+
+	// Optional external GS order for contacts: a permutation (or subset order) of contact indices.
+	std::vector<u32> customOrder;
+	// "Follow" mode for whole-step parity with a device run: the narrowphase consumes an externally ordered candidate-pair list
+	// (slots) instead of prune/classify/bucket, contacts are solved manifold by manifold in `slotOrder`, joints in `jointOrder[t]`.
+	bool usePairOverride = false;
+	std::vector<collider_pair> pairOverride;
+	std::vector<u32> slotOrder;
+	std::vector<u8> slotCounts;          // contacts per candidate slot of the last narrowphase (override mode)
+	std::vector<u32> jointOrder[6];
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Mass properties — physics.cpp:1416-1519 (per collider) + rigid_body.cpp:29-81 (combine)
+// ---------------------------------------------------------------------------------------------------
+struct physics_properties { mat3 inertia; vec3 cog; float mass; };
+
+static physics_properties calculatePhysicsProperties(const collider_union& c)
+{
+	physics_properties result;
+	switch (c.type)
+	{
+		case collider_type_sphere:
+		{
+			bounding_sphere s = c.sphere();
+			result.mass = sphereVolume(s.radius) * c.material.density;
+			result.cog = s.center;
+			result.inertia = mat3::identity() * (2.f / 5.f * result.mass * s.radius * s.radius);
+		} break;
+		case collider_type_capsule:
+		{
+			bounding_capsule cap = c.capsule();
+			vec3 axis = cap.positionA - cap.positionB;
+			if (axis.y < 0.f) { axis *= -1.f; }
+			float height = length(axis);
+			axis *= (1.f / height);
+			quat rotation = rotateFromTo(vec3(0.f, 1.f, 0.f), axis);
+			mat3 rot = quaternionToMat3(rotation);
+			result.mass = capsuleVolume(cap) * c.material.density;
+			result.cog = (cap.positionA + cap.positionB) * 0.5f;
+			float sqRadius = cap.radius * cap.radius;
+			float sqRadiusPI = M_PI_F * sqRadius;
+			float cylinderMass = c.material.density * sqRadiusPI * height;
+			float hemiSphereMass = c.material.density * 2.f / 3.f * sqRadiusPI * cap.radius;
+			float sqCapsuleHeight = height * height;
+			mat3 I;
+			I.m11 = sqRadius * cylinderMass * 0.5f;
+			I.m00 = I.m22 = I.m11 * 0.5f + cylinderMass * sqCapsuleHeight / 12.f;
+			float temp0 = hemiSphereMass * 2.f * sqRadius / 5.f;
+			I.m11 += temp0 * 2.f;
+			float temp1 = height * 0.5f;
+			float temp2 = temp0 + hemiSphereMass * (temp1 * temp1 + 3.f / 8.f * sqCapsuleHeight);
+			I.m00 += temp2 * 2.f;
+			I.m22 += temp2 * 2.f;
+			result.inertia = transpose(rot) * I * rot;
+		} break;
+		case collider_type_cylinder:
+		{
+			bounding_cylinder cyl = c.cylinder();
+			vec3 axis = cyl.positionA - cyl.positionB;
+			if (axis.y < 0.f) { axis *= -1.f; }
+			float height = length(axis);
+			axis *= (1.f / height);
+			quat rotation = rotateFromTo(vec3(0.f, 1.f, 0.f), axis);
+			mat3 rot = quaternionToMat3(rotation);
+			result.mass = cylinderVolume(cyl) * c.material.density;
+			result.cog = (cyl.positionA + cyl.positionB) * 0.5f;
+			float sqRadius = cyl.radius * cyl.radius;
+			float sqHeight = height * height;
+			mat3 I;
+			I.m11 = sqRadius * result.mass * 0.5f;
+			I.m00 = I.m22 = 1.f / 12.f * result.mass * (3.f * sqRadius + sqHeight);
+			result.inertia = transpose(rot) * I * rot;
+		} break;
+		case collider_type_aabb:
+		{
+			bounding_box b = c.aabb();
+			result.mass = b.volume() * c.material.density;
+			result.cog = b.getCenter();
+			vec3 diameter = b.getRadius() * 2.f;
+			result.inertia = mat3::zero();
+			result.inertia.m00 = 1.f / 12.f * result.mass * (diameter.y * diameter.y + diameter.z * diameter.z);
+			result.inertia.m11 = 1.f / 12.f * result.mass * (diameter.x * diameter.x + diameter.z * diameter.z);
+			result.inertia.m22 = 1.f / 12.f * result.mass * (diameter.x * diameter.x + diameter.y * diameter.y);
+		} break;
+		case collider_type_obb:
+		{
+			bounding_oriented_box o = c.obb();
+			result.mass = o.volume() * c.material.density;
+			result.cog = o.center;
+			vec3 diameter = o.radius * 2.f;
+			mat3 I = mat3::zero();
+			I.m00 = 1.f / 12.f * result.mass * (diameter.y * diameter.y + diameter.z * diameter.z);
+			I.m11 = 1.f / 12.f * result.mass * (diameter.x * diameter.x + diameter.z * diameter.z);
+			I.m22 = 1.f / 12.f * result.mass * (diameter.x * diameter.x + diameter.y * diameter.y);
+			mat3 rot = quaternionToMat3(o.rotation);
+			result.inertia = transpose(rot) * I * rot;
+		} break;
+		default: result.mass = 0.f; result.inertia = mat3::zero(); break;
+	}
+	return result;
+}
+
+// rigid_body.cpp:29-81
+static void recalculateProperties(world& w, body& rb)
+{
+	if (rb.invMass == 0.f) { return; } // kinematic
+	u32 numColliders = (u32)rb.colliders.size();
+	if (!numColliders) { return; }
+	std::vector<physics_properties> properties(numColliders);
+	for (u32 i = 0; i < numColliders; ++i) // newest first, like the reference's intrusive list
+	{
+		properties[i] = calculatePhysicsProperties(w.colliders[rb.colliders[numColliders - 1 - i]].local);
+	}
+	mat3 inertia = mat3::zero();
+	vec3 cog(0.f);
+	float mass = 0.f;
+	for (u32 i = 0; i < numColliders; ++i) { mass += properties[i].mass; cog += properties[i].cog * properties[i].mass; }
+	rb.invMass = 1.f / mass;
+	rb.localCOGPosition = cog = cog * rb.invMass;
+	for (u32 i = 0; i < numColliders; ++i)
+	{
+		vec3 r = properties[i].cog - cog;
+		inertia += properties[i].inertia + (mat3::identity() * dot(r, r) - outerProduct(r, r)) * properties[i].mass;
+	}
+	rb.invInertia = invert(inertia);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// getWorldSpaceColliders — physics.cpp:631-756
+// ---------------------------------------------------------------------------------------------------
+static void getWorldSpaceColliders(world& w)
+{
+	u32 n = (u32)w.colliders.size();
+	u32 dummyRigidBodyIndex = (u32)w.bodies.size();
+	w.worldSpaceAABBs.resize(n);
+	w.worldSpaceColliders.resize(n);
+	for (u32 i = 0; i < n; ++i)
+	{
+		const collider& c = w.colliders[i];
+		bounding_box& bb = w.worldSpaceAABBs[i];
+		collider_union& col = w.worldSpaceColliders[i];
+		const trs& transform = (c.parent != STATIC_BODY) ? w.bodies[c.parent].transform1 : c.staticTransform;
+		col = c.local;
+		if (c.parent != STATIC_BODY) { col.objectIndex = c.parent; col.objectType = physics_object_type_rigid_body; }
+		else { col.objectIndex = dummyRigidBodyIndex; col.objectType = physics_object_type_static_collider; }
+		switch (c.local.type)
+		{
+			case collider_type_sphere:
+			{
+				bounding_sphere s = c.local.sphere();
+				vec3 center = transform.position + transform.rotation * s.center;
+				bb = bounding_box::fromCenterRadius(center, s.radius);
+				col.set(bounding_sphere{ center, s.radius });
+			} break;
+			case collider_type_capsule:
+			{
+				bounding_capsule cap = c.local.capsule();
+				vec3 posA = transform.rotation * cap.positionA + transform.position;
+				vec3 posB = transform.rotation * cap.positionB + transform.position;
+				vec3 radius3(cap.radius);
+				bb = bounding_box::negativeInfinity();
+				bb.grow(posA + radius3); bb.grow(posA - radius3); bb.grow(posB + radius3); bb.grow(posB - radius3);
+				col.set(bounding_capsule{ posA, posB, cap.radius });
+			} break;
+			case collider_type_cylinder:
+			{
+				bounding_cylinder cyl = c.local.cylinder();
+				vec3 posA = transform.rotation * cyl.positionA + transform.position;
+				vec3 posB = transform.rotation * cyl.positionB + transform.position;
+				vec3 a = posB - posA;
+				float aa = dot(a, a);
+				float x = 1.f - a.x * a.x / aa, y = 1.f - a.y * a.y / aa, z = 1.f - a.z * a.z / aa;
+				x = sqrtf(std::max(0.f, x)); y = sqrtf(std::max(0.f, y)); z = sqrtf(std::max(0.f, z));
+				vec3 e = cyl.radius * vec3(x, y, z);
+				bb = bounding_box::fromMinMax(vmin(posA - e, posB - e), vmax(posA + e, posB + e));
+				col.set(bounding_capsule{ posA, posB, cyl.radius });
+			} break;
+			case collider_type_aabb:
+			{
+				bounding_box b = c.local.aabb();
+				bb = b.transformToAABB(transform.rotation, transform.position);
+				if (transform.rotation == quat(0.f, 0.f, 0.f, 1.f)) { col.set(bb); }
+				else { col.type = collider_type_obb; col.set(b.transformToOBB(transform.rotation, transform.position)); }
+			} break;
+			case collider_type_obb:
+			{
+				bounding_oriented_box o = c.local.obb();
+				bb = o.transformToAABB(transform.rotation, transform.position);
+				col.set(o.transformToOBB(transform.rotation, transform.position));
+			} break;
+			default: break;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// broadphase — collision_broad.cpp:297-447 with determineOverlapsScalar (:87-166)
+// ---------------------------------------------------------------------------------------------------
+static void broadphase(world& w)
+{
+	u32 numColliders = (u32)w.colliders.size();
+	w.broadphasePairs.clear();
+	if (numColliders == 0) { return; }
+	std::vector<sap_endpoint>& endpoints = w.endpoints;
+	u32 numEndpoints = numColliders * 2;
+
+	vec3 s(0.f), s2(0.f);
+	u32 sortingAxis = w.sortingAxis;
+	w.usedSortingAxis = sortingAxis;
+	{
+		// the reference walks indirections (collider -> endpoint slots); equivalent here: scan endpoints.
+		for (u32 e = 0; e < numEndpoints; ++e)
+		{
+			sap_endpoint& ep = endpoints[e];
+			const bounding_box& aabb = w.worldSpaceAABBs[ep.collider];
+			ep.value = ep.start ? aabb.minCorner[sortingAxis] : aabb.maxCorner[sortingAxis];
+		}
+		for (u32 i = 0; i < numColliders; ++i)
+		{
+			vec3 center = w.worldSpaceAABBs[i].getCenter();
+			s += center;
+			s2 += center * center;
+		}
+	}
+	for (u32 i = 1; i < numEndpoints; ++i) // insertion sort (:387-398), stable, strict >
+	{
+		sap_endpoint key = endpoints[i];
+		u32 j = i - 1;
+		while (j != UINT32_MAX && endpoints[j].value > key.value) { endpoints[j + 1] = endpoints[j]; j = j - 1; }
+		endpoints[j + 1] = key;
+	}
+
+	// determineOverlapsScalar (:87-166)
+	std::vector<u32> activeList(numColliders), positionInActiveList(numColliders);
+	std::vector<bounding_box> activeBBs(numColliders);
+	u32 numActive = 0;
+	for (u32 i = 0; i < numEndpoints; ++i)
+	{
+		sap_endpoint ep = endpoints[i];
+		if (ep.start)
+		{
+			const bounding_box& a = w.worldSpaceAABBs[ep.collider];
+			for (u32 active = 0; active < numActive; ++active)
+			{
+				if (aabbVsAABB(a, activeBBs[active])) { w.broadphasePairs.push_back({ ep.collider, activeList[active] }); }
+			}
+			positionInActiveList[ep.collider] = numActive;
+			activeBBs[numActive] = a;
+			activeList[numActive++] = ep.collider;
+		}
+		else
+		{
+			u32 pos = positionInActiveList[ep.collider];
+			--numActive;
+			u32 last = activeList[numActive];
+			positionInActiveList[last] = pos;
+			activeList[pos] = activeList[numActive];
+			activeBBs[pos] = activeBBs[numActive];
+		}
+	}
+	vec3 variance = s2 - s * s / (float)numColliders;
+	w.sortingAxis = (variance.x > variance.y) ? ((variance.x > variance.z) ? 0 : 2) : ((variance.y > variance.z) ? 1 : 2);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// narrowphase — collision_narrow.cpp:2328-2603 (collision pairs only; triggers/force fields are row N2)
+// ---------------------------------------------------------------------------------------------------
+static u32 packFrictionRestitution(const collider_union& A, const collider_union& B) // :2231-2237
+{
+	float friction = clamp01(sqrtf(A.material.friction * B.material.friction));
+	float restitution = clamp01(std::max(A.material.restitution, B.material.restitution));
+	return ((u32)(friction * 0xFFFF) << 16) | (u32)(restitution * 0xFFFF);
+}
+
+static void narrowphaseOverride(world& w)
+{
+	const collider_union* cols = w.worldSpaceColliders.data();
+	w.contacts.clear(); w.contactBodyPairs.clear(); w.collidingPairs.clear(); w.contactCountPerCollision.clear(); w.contactCollisionIndex.clear();
+	w.slotCounts.assign(w.pairOverride.size(), 0);
+	std::vector<u32> slotStart(w.pairOverride.size(), 0);
+	for (size_t s = 0; s < w.pairOverride.size(); ++s)
+	{
+		collider_pair pair = w.pairOverride[s];
+		const collider_union& A = cols[pair.colliderA];
+		const collider_union& B = cols[pair.colliderB];
+		contact_manifold contact; contact.numContacts = 0;
+		slotStart[s] = (u32)w.contacts.size();
+		if (intersectColliders(A, B, contact))
+		{
+			u32 fr = packFrictionRestitution(A, B);
+			u32 collisionIndex = (u32)w.collidingPairs.size();
+			w.collidingPairs.push_back(pair);
+			w.contactCountPerCollision.push_back((u8)contact.numContacts);
+			w.slotCounts[s] = (u8)contact.numContacts;
+			for (u32 k = 0; k < contact.numContacts; ++k)
+			{
+				collision_contact c;
+				c.normal = contact.collisionNormal; c.penetrationDepth = contact.contacts[k].penetrationDepth; c.point = contact.contacts[k].point; c.friction_restitution = fr;
+				w.contacts.push_back(c);
+				w.contactBodyPairs.push_back({ A.objectIndex, B.objectIndex });
+				w.contactCollisionIndex.push_back(collisionIndex);
+			}
+		}
+	}
+	w.customOrder.clear();
+	for (u32 s : w.slotOrder) { if (s < slotStart.size()) for (u32 k = 0; k < w.slotCounts[s]; ++k) w.customOrder.push_back(slotStart[s] + k); }
+}
+
+static void narrowphasePairs(world& w, const collider_pair* inPairs, u32 numPairs)
+{
+	const collider_union* cols = w.worldSpaceColliders.data();
+	std::vector<collider_pair> kept;
+	kept.reserve(numPairs);
+	u32 countMatrix[collider_type_count][collider_type_count] = {};
+	for (u32 i = 0; i < numPairs; ++i) // prune, classify, count (:2346-2397)
+	{
+		collider_pair pair = inPairs[i];
+		const collider_union* a = cols + pair.colliderA;
+		const collider_union* b = cols + pair.colliderB;
+		if (a->objectType != physics_object_type_rigid_body && b->objectType != physics_object_type_rigid_body) { continue; }
+		if (a->objectType == physics_object_type_rigid_body && b->objectType == physics_object_type_rigid_body && a->objectIndex == b->objectIndex) { continue; }
+		pair = (a->type < b->type) ? pair : collider_pair{ pair.colliderB, pair.colliderA }; // NB swaps on equal types (:2374)
+		a = cols + pair.colliderA; b = cols + pair.colliderB;
+		++countMatrix[a->type][b->type];
+		kept.push_back(pair);
+	}
+	u32 offsetMatrix[collider_type_count][collider_type_count] = {};
+	u32 total = 0;
+	for (u32 i = 0; i < collider_type_count; ++i) for (u32 j = i; j < collider_type_count; ++j) { offsetMatrix[i][j] = total; total += countMatrix[i][j]; }
+	std::vector<collider_pair> sorted(kept.size());
+	u32 writeMatrix[collider_type_count][collider_type_count] = {};
+	for (const collider_pair& pair : kept) // stable bucket sort (:2431-2440)
+	{
+		u32 ta = cols[pair.colliderA].type, tb = cols[pair.colliderB].type;
+		sorted[offsetMatrix[ta][tb] + writeMatrix[ta][tb]++] = pair;
+	}
+
+	w.contacts.clear(); w.contactBodyPairs.clear(); w.collidingPairs.clear(); w.contactCountPerCollision.clear(); w.contactCollisionIndex.clear();
+	for (const collider_pair& pair : sorted) // dispatch in bucket order (:2473-2570), collisionScalar (:2285-2302)
+	{
+		const collider_union& A = cols[pair.colliderA];
+		const collider_union& B = cols[pair.colliderB];
+		contact_manifold contact;
+		contact.numContacts = 0;
+		if (intersectColliders(A, B, contact))
+		{
+			u32 fr = packFrictionRestitution(A, B); // writeScalarContact (:2221-2253)
+			u32 collisionIndex = (u32)w.collidingPairs.size();
+			w.collidingPairs.push_back(pair);
+			w.contactCountPerCollision.push_back((u8)contact.numContacts);
+			for (u32 k = 0; k < contact.numContacts; ++k)
+			{
+				collision_contact c;
+				c.normal = contact.collisionNormal;
+				c.penetrationDepth = contact.contacts[k].penetrationDepth;
+				c.point = contact.contacts[k].point;
+				c.friction_restitution = fr;
+				w.contacts.push_back(c);
+				w.contactBodyPairs.push_back({ A.objectIndex, B.objectIndex });
+				w.contactCollisionIndex.push_back(collisionIndex);
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Integrators — rigid_body.cpp:95-142
+// ---------------------------------------------------------------------------------------------------
+static void applyGravityAndIntegrateForces(body& rb, rigid_body_global_state& global, const trs& transform, float dt)
+{
+	global.rotation = transform.rotation;
+	global.position = transform.position + transform.rotation * rb.localCOGPosition;
+	mat3 rot = quaternionToMat3(global.rotation);
+	global.invInertia = rot * rb.invInertia * transpose(rot);
+	global.invMass = rb.invMass;
+	if (rb.invMass > 0.f) { rb.forceAccumulator.y += (GRAVITY / rb.invMass * rb.gravityFactor); }
+	vec3 linearAcceleration = rb.forceAccumulator * rb.invMass;
+	vec3 angularAcceleration = global.invInertia * rb.torqueAccumulator;
+	rb.linearVelocity += linearAcceleration * dt;
+	rb.angularVelocity += angularAcceleration * dt;
+	rb.linearVelocity *= 1.f / (1.f + dt * rb.linearDamping);
+	rb.angularVelocity *= 1.f / (1.f + dt * rb.angularDamping);
+	global.linearVelocity = rb.linearVelocity;
+	global.angularVelocity = rb.angularVelocity;
+	global.localCOGPosition = rb.localCOGPosition;
+}
+static void integrateVelocity(body& rb, const rigid_body_global_state& global, trs& transform, float dt)
+{
+	rb.linearVelocity = global.linearVelocity;
+	rb.angularVelocity = global.angularVelocity;
+	quat deltaRot(0.5f * rb.angularVelocity.x, 0.5f * rb.angularVelocity.y, 0.5f * rb.angularVelocity.z, 0.f);
+	deltaRot = deltaRot * global.rotation;
+	quat rotation = normalize(global.rotation + (deltaRot * dt));
+	vec3 position = global.position + rb.linearVelocity * dt;
+	rb.forceAccumulator = vec3(0.f);
+	rb.torqueAccumulator = vec3(0.f);
+	transform.rotation = rotation;
+	transform.position = position - rotation * rb.localCOGPosition;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// physicsStepInternal — physics.cpp:1180-1362
+// ---------------------------------------------------------------------------------------------------
+static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
+{
+	u32 numRigidBodies = (u32)w.bodies.size();
+	if (numRigidBodies == 0) { return; }
+	u32 dummyRigidBodyIndex = numRigidBodies;
+
+	getWorldSpaceColliders(w);
+	broadphase(w);
+	if (w.usePairOverride) { narrowphaseOverride(w); }
+	else { narrowphasePairs(w, w.broadphasePairs.data(), (u32)w.broadphasePairs.size()); }
+
+	w.rbGlobal.resize(numRigidBodies + 1);
+	for (u32 i = 0; i < numRigidBodies; ++i) { applyGravityAndIntegrateForces(w.bodies[i], w.rbGlobal[i], w.bodies[i].transform1, dt); }
+	memset(&w.rbGlobal[dummyRigidBodyIndex], 0, sizeof(rigid_body_global_state)); // :1279
+	w.rbGlobalPreSolve = w.rbGlobal;
+	rigid_body_global_state* rbs = w.rbGlobal.data();
+
+	// constraint_solver::initialize (constraints.cpp:3711-3746): joints scalar (joint SIMD variants schedule with
+	// dummy = UINT16_MAX, see solveJointsInSlotOrder), contacts per `mode`.
+	std::vector<distance_constraint_update> dU(w.distanceConstraints.size());
+	std::vector<ball_constraint_update> bU(w.ballConstraints.size());
+	std::vector<fixed_constraint_update> fU(w.fixedConstraints.size());
+	std::vector<hinge_constraint_update> hU(w.hingeConstraints.size());
+	std::vector<cone_twist_constraint_update> cU(w.coneTwistConstraints.size());
+	std::vector<slider_constraint_update> sU(w.sliderConstraints.size());
+	for (size_t i = 0; i < dU.size(); ++i) initializeDistanceConstraint(dU[i], rbs, w.distanceConstraints[i], w.distancePairs[i], dt);
+	for (size_t i = 0; i < bU.size(); ++i) initializeBallConstraint(bU[i], rbs, w.ballConstraints[i], w.ballPairs[i], dt);
+	for (size_t i = 0; i < fU.size(); ++i) initializeFixedConstraint(fU[i], rbs, w.fixedConstraints[i], w.fixedPairs[i], dt);
+	for (size_t i = 0; i < hU.size(); ++i) initializeHingeConstraint(hU[i], rbs, w.hingeConstraints[i], w.hingePairs[i], dt);
+	for (size_t i = 0; i < cU.size(); ++i) initializeConeTwistConstraint(cU[i], rbs, w.coneTwistConstraints[i], w.coneTwistPairs[i], dt);
+	for (size_t i = 0; i < sU.size(); ++i) initializeSliderConstraint(sU[i], rbs, w.sliderConstraints[i], w.sliderPairs[i], dt);
+
+	// Joint GS order: scalar = storage order; wide8 = scheduler output order with dummy UINT16_MAX (constraints.cpp:271,
+	// 535, 830, 1314, 2077, 2853); duplicated padding lanes are idempotent re-solves of lane 0 and are skipped.
+	auto jointOrder = [&](const std::vector<constraint_body_pair>& pairs)
+	{
+		std::vector<u32> order;
+		if (mode == solver_wide8)
+		{
+			std::vector<sched_slot> slots;
+			scheduleConstraintsSIMD(pairs.data(), (u32)pairs.size(), 0xFFFFu, slots);
+			for (const sched_slot& s : slots)
+			{
+				for (u32 l = 0; l < SCHED_W; ++l) { if (l == 0 || s.indices[l] != s.indices[0]) order.push_back(s.indices[l]); }
+			}
+		}
+		else { for (u32 i = 0; i < pairs.size(); ++i) order.push_back(i); }
+		return order;
+	};
+	std::vector<u32> dO = jointOrder(w.distancePairs), bO = jointOrder(w.ballPairs), fO = jointOrder(w.fixedPairs);
+	std::vector<u32> hO = jointOrder(w.hingePairs), cO = jointOrder(w.coneTwistPairs), sO = jointOrder(w.sliderPairs);
+	if (w.usePairOverride) // follow mode: external joint orders (same size as the joint arrays)
+	{
+		std::vector<u32>* os[6] = { &dO, &bO, &fO, &hO, &cO, &sO };
+		for (int t = 0; t < 6; ++t) if (w.jointOrder[t].size() == os[t]->size()) *os[t] = w.jointOrder[t];
+	}
+
+	u32 numContacts = (u32)w.contacts.size();
+	std::vector<simd_collision_constraint_batch> batches;
+	w.contactConstraints.clear(); w.contactSlots.clear();
+	if (mode == solver_wide8)
+	{
+		scheduleConstraintsSIMD(w.contactBodyPairs.data(), numContacts, dummyRigidBodyIndex, w.contactSlots);
+		initializeCollisionBatchesWide(batches, w.contactSlots, rbs, w.contacts.data(), w.contactBodyPairs.data(), dt);
+	}
+	else
+	{
+		w.contactConstraints.resize(numContacts);
+		for (u32 i = 0; i < numContacts; ++i) initializeCollisionConstraint(w.contactConstraints[i], rbs, w.contacts[i], w.contactBodyPairs[i], dt);
+	}
+
+	for (u32 it = 0; it < iterations; ++it) // solveOneIteration (constraints.cpp:3748-3772)
+	{
+		for (u32 i : dO) solveDistanceConstraint(dU[i], rbs);
+		for (u32 i : bO) solveBallConstraint(bU[i], rbs);
+		for (u32 i : fO) solveFixedConstraint(fU[i], rbs);
+		for (u32 i : hO) solveHingeConstraint(hU[i], rbs);
+		for (u32 i : cO) solveConeTwistConstraint(cU[i], rbs);
+		for (u32 i : sO) solveSliderConstraint(sU[i], rbs);
+		if (mode == solver_wide8) { solveCollisionBatchesWide(batches, rbs); }
+		else if (mode == solver_custom_order)
+		{
+			for (u32 ci : w.customOrder) { if (ci < numContacts) solveCollisionConstraint(w.contactConstraints[ci], w.contacts[ci], w.contactBodyPairs[ci], rbs); }
+		}
+		else
+		{
+			for (u32 i = 0; i < numContacts; ++i) solveCollisionConstraint(w.contactConstraints[i], w.contacts[i], w.contactBodyPairs[i], rbs);
+		}
+	}
+
+	for (u32 i = 0; i < numRigidBodies; ++i) { integrateVelocity(w.bodies[i], w.rbGlobal[i], w.bodies[i].transform1, dt); }
+}
+
+// physics.cpp:1364-1413
+static void physicsStep(world& w, float& timer, const physics_settings& settings, u32 mode, float dt)
+{
+	if (settings.fixedFrameRate)
+	{
+		const float physicsFixedTimeStep = 1.f / (float)settings.frameRate;
+		timer += dt;
+		u32 physicsIterations = 0;
+		if (timer >= physicsFixedTimeStep)
+		{
+			for (body& b : w.bodies) { b.transform0 = b.transform1; }
+			while (timer >= physicsFixedTimeStep && physicsIterations++ < settings.maxPhysicsIterationsPerFrame)
+			{
+				physicsStepInternal(w, settings.numRigidSolverIterations, mode, physicsFixedTimeStep);
+				timer -= physicsFixedTimeStep;
+			}
+		}
+		if (timer >= physicsFixedTimeStep) { timer = fmodf(timer, physicsFixedTimeStep); }
+		float t = timer / physicsFixedTimeStep;
+		for (body& b : w.bodies) // lerp(trs) (core/math.h:676-683): position lerp, rotation nlerp
+		{
+			b.transform.position = lerp(b.transform0.position, b.transform1.position, t);
+			quat l = b.transform0.rotation, u = b.transform1.rotation;
+			quat q(l.x + t * (u.x - l.x), l.y + t * (u.y - l.y), l.z + t * (u.z - l.z), l.w + t * (u.w - l.w));
+			b.transform.rotation = normalize(q);
+		}
+	}
+	else
+	{
+		physicsStepInternal(w, settings.numRigidSolverIterations, mode, dt);
+		for (body& b : w.bodies) { b.transform = b.transform1; }
+	}
+}
+
+} // namespace orc
+
+// =====================================================================================================
+// C API (ctypes-friendly).  Mirrors include/mi_physics.h so the parity tests drive both the same way.
+// =====================================================================================================
+using namespace orc;
+extern "C" {
+
+world* orc_world_create() { return new world(); }
+void orc_world_destroy(world* w) { delete w; }
+
+// rigid_body.cpp:6-27 + scene.h:69-84
+u32 orc_add_body(world* w, int kinematic, float gravityFactor, float linearDamping, float angularDamping, const float* pos, const float* rot)
+{
+	body b;
+	if (kinematic) { b.invMass = 0.f; b.invInertia = mat3::zero(); }
+	else { b.invMass = 1.f; b.invInertia = mat3::identity(); }
+	b.gravityFactor = gravityFactor; b.linearDamping = linearDamping; b.angularDamping = angularDamping;
+	b.transform.position = vec3(pos[0], pos[1], pos[2]);
+	b.transform.rotation = quat(rot[0], rot[1], rot[2], rot[3]);
+	b.transform0 = b.transform1 = b.transform;
+	w->bodies.push_back(b);
+	return (u32)w->bodies.size() - 1;
+}
+
+static u32 addColliderCommon(world* w, u32 parent, u32 type, const float* shape, const float* material, const float* pos, const float* rot)
+{
+	collider c;
+	memset(&c.local, 0, sizeof(c.local));
+	for (u32 i = 0; i < 10; ++i) c.local.shape[i] = shape[i];
+	c.local.material = physics_material{ material[0], material[1], material[2] };
+	c.local.type = type;
+	c.parent = parent;
+	c.staticTransform.position = pos ? vec3(pos[0], pos[1], pos[2]) : vec3(0.f);
+	c.staticTransform.rotation = rot ? quat(rot[0], rot[1], rot[2], rot[3]) : quat(0.f, 0.f, 0.f, 1.f);
+	u32 id = (u32)w->colliders.size();
+	w->colliders.push_back(c);
+	w->endpoints.push_back(sap_endpoint{ 0.f, id, true });   // addColliderToBroadphase (collision_broad.cpp:27-40)
+	w->endpoints.push_back(sap_endpoint{ 0.f, id, false });
+	if (parent != STATIC_BODY)
+	{
+		w->bodies[parent].colliders.push_back(id);
+		recalculateProperties(*w, w->bodies[parent]); // scene.h:60-63
+	}
+	return id;
+}
+u32 orc_add_collider(world* w, u32 bodyId, u32 type, const float* shape, const float* material) { return addColliderCommon(w, bodyId, type, shape, material, 0, 0); }
+u32 orc_add_static_collider(world* w, u32 type, const float* shape, const float* material, const float* pos, const float* rot) { return addColliderCommon(w, STATIC_BODY, type, shape, material, pos, rot); }
+
+static vec3 v3(const float* p) { return vec3(p[0], p[1], p[2]); }
+
+// physics.cpp:128-333
+u32 orc_add_distance_constraint_local(world* w, u32 a, u32 b, const float* la, const float* lb, float distance)
+{
+	w->distanceConstraints.push_back(distance_constraint{ v3(la), v3(lb), distance });
+	w->distancePairs.push_back({ a, b });
+	return (u32)w->distanceConstraints.size() - 1;
+}
+u32 orc_add_distance_constraint_global(world* w, u32 a, u32 b, const float* ga, const float* gb)
+{
+	vec3 la = inverseTransformPosition(w->bodies[a].transform, v3(ga));
+	vec3 lb = inverseTransformPosition(w->bodies[b].transform, v3(gb));
+	float distance = length(v3(ga) - v3(gb));
+	return orc_add_distance_constraint_local(w, a, b, &la.x, &lb.x, distance);
+}
+u32 orc_add_ball_constraint_local(world* w, u32 a, u32 b, const float* la, const float* lb)
+{
+	w->ballConstraints.push_back(ball_constraint{ v3(la), v3(lb) });
+	w->ballPairs.push_back({ a, b });
+	return (u32)w->ballConstraints.size() - 1;
+}
+u32 orc_add_ball_constraint_global(world* w, u32 a, u32 b, const float* g)
+{
+	vec3 la = inverseTransformPosition(w->bodies[a].transform, v3(g));
+	vec3 lb = inverseTransformPosition(w->bodies[b].transform, v3(g));
+	return orc_add_ball_constraint_local(w, a, b, &la.x, &lb.x);
+}
+u32 orc_add_fixed_constraint_global(world* w, u32 a, u32 b, const float* g)
+{
+	const trs& tA = w->bodies[a].transform; const trs& tB = w->bodies[b].transform;
+	fixed_constraint c;
+	c.localAnchorA = inverseTransformPosition(tA, v3(g));
+	c.localAnchorB = inverseTransformPosition(tB, v3(g));
+	c.initialInvRotationDifference = conjugate(tB.rotation) * tA.rotation;
+	w->fixedConstraints.push_back(c);
+	w->fixedPairs.push_back({ a, b });
+	return (u32)w->fixedConstraints.size() - 1;
+}
+u32 orc_add_hinge_constraint_global(world* w, u32 a, u32 b, const float* anchor, const float* axis, float minLimit, float maxLimit)
+{
+	const trs& tA = w->bodies[a].transform; const trs& tB = w->bodies[b].transform;
+	hinge_constraint c;
+	c.localAnchorA = inverseTransformPosition(tA, v3(anchor));
+	c.localAnchorB = inverseTransformPosition(tB, v3(anchor));
+	c.localHingeAxisA = inverseTransformDirection(tA, v3(axis));
+	c.localHingeAxisB = inverseTransformDirection(tB, v3(axis));
+	getTangents(c.localHingeAxisA, c.localHingeTangentA, c.localHingeBitangentA);
+	c.localHingeTangentB = conjugate(tB.rotation) * (tA.rotation * c.localHingeTangentA);
+	c.minRotationLimit = minLimit; c.maxRotationLimit = maxLimit;
+	c.motorType = constraint_velocity_motor; c.motorVelocity = 0.f; c.maxMotorTorque = -1.f;
+	w->hingeConstraints.push_back(c);
+	w->hingePairs.push_back({ a, b });
+	return (u32)w->hingeConstraints.size() - 1;
+}
+u32 orc_add_cone_twist_constraint_global(world* w, u32 a, u32 b, const float* anchor, const float* axis, float swingLimit, float twistLimit)
+{
+	const trs& tA = w->bodies[a].transform; const trs& tB = w->bodies[b].transform;
+	cone_twist_constraint c;
+	c.localAnchorA = inverseTransformPosition(tA, v3(anchor));
+	c.localAnchorB = inverseTransformPosition(tB, v3(anchor));
+	c.swingLimit = swingLimit; c.twistLimit = twistLimit;
+	c.localLimitAxisA = inverseTransformDirection(tA, v3(axis));
+	c.localLimitAxisB = inverseTransformDirection(tB, v3(axis));
+	getTangents(c.localLimitAxisA, c.localLimitTangentA, c.localLimitBitangentA);
+	c.localLimitTangentB = conjugate(tB.rotation) * (tA.rotation * c.localLimitTangentA);
+	c.swingMotorType = constraint_velocity_motor; c.swingMotorVelocity = 0.f; c.maxSwingMotorTorque = -1.f; c.swingMotorAxis = 0.f;
+	c.twistMotorType = constraint_velocity_motor; c.twistMotorVelocity = 0.f; c.maxTwistMotorTorque = -1.f;
+	w->coneTwistConstraints.push_back(c);
+	w->coneTwistPairs.push_back({ a, b });
+	return (u32)w->coneTwistConstraints.size() - 1;
+}
+u32 orc_add_slider_constraint_global(world* w, u32 a, u32 b, const float* anchor, const float* axis, float minLimit, float maxLimit)
+{
+	const trs& tA = w->bodies[a].transform; const trs& tB = w->bodies[b].transform;
+	slider_constraint c;
+	c.localAnchorA = inverseTransformPosition(tA, v3(anchor));
+	c.localAnchorB = inverseTransformPosition(tB, v3(anchor));
+	c.localAxisA = inverseTransformDirection(tA, v3(axis));
+	c.initialInvRotationDifference = conjugate(tB.rotation) * tA.rotation;
+	c.negDistanceLimit = minLimit; c.posDistanceLimit = maxLimit;
+	c.motorType = constraint_velocity_motor; c.motorVelocity = 0.f; c.maxMotorForce = -1.f;
+	w->sliderConstraints.push_back(c);
+	w->sliderPairs.push_back({ a, b });
+	return (u32)w->sliderConstraints.size() - 1;
+}
+
+// getConstraint() mutable access (physics.h:248-253): type 0..5 = distance..slider (constraints.h:14-28)
+static void* constraintPtr(world* w, u32 type, u32 id, u32* size)
+{
+	switch (type)
+	{
+		case 0: *size = sizeof(distance_constraint); return id < w->distanceConstraints.size() ? &w->distanceConstraints[id] : 0;
+		case 1: *size = sizeof(ball_constraint); return id < w->ballConstraints.size() ? &w->ballConstraints[id] : 0;
+		case 2: *size = sizeof(fixed_constraint); return id < w->fixedConstraints.size() ? &w->fixedConstraints[id] : 0;
+		case 3: *size = sizeof(hinge_constraint); return id < w->hingeConstraints.size() ? &w->hingeConstraints[id] : 0;
+		case 4: *size = sizeof(cone_twist_constraint); return id < w->coneTwistConstraints.size() ? &w->coneTwistConstraints[id] : 0;
+		case 5: *size = sizeof(slider_constraint); return id < w->sliderConstraints.size() ? &w->sliderConstraints[id] : 0;
+	}
+	return 0;
+}
+int orc_constraint_get(world* w, u32 type, u32 id, void* pod) { u32 s; void* p = constraintPtr(w, type, id, &s); if (!p) return 1; memcpy(pod, p, s); return 0; }
+int orc_constraint_set(world* w, u32 type, u32 id, const void* pod) { u32 s; void* p = constraintPtr(w, type, id, &s); if (!p) return 1; memcpy(p, pod, s); return 0; }
+
+int orc_apply_force_torque(world* w, u32 b, const float* f, const float* t)
+{
+	if (b >= w->bodies.size()) return 1;
+	w->bodies[b].forceAccumulator += v3(f); w->bodies[b].torqueAccumulator += v3(t);
+	return 0;
+}
+int orc_set_velocity(world* w, u32 b, const float* lin, const float* ang)
+{
+	if (b >= w->bodies.size()) return 1;
+	w->bodies[b].linearVelocity = v3(lin); w->bodies[b].angularVelocity = v3(ang);
+	return 0;
+}
+
+int orc_step(world* w, float* timer, const physics_settings* settings, u32 mode, float dt) { physicsStep(*w, *timer, *settings, mode, dt); return 0; }
+int orc_step_internal(world* w, u32 iterations, u32 mode, float dt) { physicsStepInternal(*w, iterations, mode, dt); return 0; }
+void orc_set_custom_order(world* w, const u32* order, u32 n) { w->customOrder.assign(order, order + n); }
+// Follow mode (see struct world): ordered candidate pairs + manifold execution order; n = 0 switches it off.
+void orc_set_follow(world* w, const u32* pairs2, u32 numPairs, const u32* slotOrder, u32 numOrder)
+{
+	w->usePairOverride = numPairs > 0 || numOrder > 0 || pairs2 != 0;
+	w->pairOverride.assign((const collider_pair*)pairs2, (const collider_pair*)pairs2 + numPairs);
+	w->slotOrder.assign(slotOrder, slotOrder + numOrder);
+}
+void orc_clear_follow(world* w) { w->usePairOverride = false; }
+void orc_set_joint_order(world* w, u32 type, const u32* order, u32 n) { if (type < 6) w->jointOrder[type].assign(order, order + n); }
+u32 orc_read_slot_counts(world* w, u8* out) { memcpy(out, w->slotCounts.data(), w->slotCounts.size()); return (u32)w->slotCounts.size(); }
+
+u32 orc_num_bodies(world* w) { return (u32)w->bodies.size(); }
+u32 orc_num_colliders(world* w) { return (u32)w->colliders.size(); }
+u32 orc_num_pairs(world* w) { return (u32)w->broadphasePairs.size(); }
+u32 orc_num_contacts(world* w) { return (u32)w->contacts.size(); }
+u32 orc_num_collisions(world* w) { return (u32)w->collidingPairs.size(); }
+u32 orc_sorting_axis_used(world* w) { return w->usedSortingAxis; }
+u32 orc_sorting_axis_next(world* w) { return w->sortingAxis; }
+
+// which: 0 = interpolated transform, 1 = physics_transform1, 2 = physics_transform0
+void orc_read_transforms(world* w, u32 which, float* out7)
+{
+	for (size_t i = 0; i < w->bodies.size(); ++i)
+	{
+		const trs& t = which == 0 ? w->bodies[i].transform : (which == 1 ? w->bodies[i].transform1 : w->bodies[i].transform0);
+		float* o = out7 + 7 * i;
+		o[0] = t.position.x; o[1] = t.position.y; o[2] = t.position.z;
+		o[3] = t.rotation.x; o[4] = t.rotation.y; o[5] = t.rotation.z; o[6] = t.rotation.w;
+	}
+}
+void orc_read_velocities(world* w, float* out6)
+{
+	for (size_t i = 0; i < w->bodies.size(); ++i)
+	{
+		float* o = out6 + 6 * i; const body& b = w->bodies[i];
+		o[0] = b.linearVelocity.x; o[1] = b.linearVelocity.y; o[2] = b.linearVelocity.z;
+		o[3] = b.angularVelocity.x; o[4] = b.angularVelocity.y; o[5] = b.angularVelocity.z;
+	}
+}
+// localCOG(3) invMass(1) invInertia(9, column-major like the reference's mat3)
+void orc_read_mass_properties(world* w, float* out13)
+{
+	for (size_t i = 0; i < w->bodies.size(); ++i)
+	{
+		float* o = out13 + 13 * i; const body& b = w->bodies[i];
+		o[0] = b.localCOGPosition.x; o[1] = b.localCOGPosition.y; o[2] = b.localCOGPosition.z; o[3] = b.invMass;
+		memcpy(o + 4, b.invInertia.m(), 36);
+	}
+}
+void orc_read_world_colliders(world* w, void* outColliders64, float* outAABBs6)
+{
+	memcpy(outColliders64, w->worldSpaceColliders.data(), w->worldSpaceColliders.size() * sizeof(collider_union));
+	memcpy(outAABBs6, w->worldSpaceAABBs.data(), w->worldSpaceAABBs.size() * sizeof(bounding_box));
+}
+void orc_read_pairs(world* w, u32* out2) { memcpy(out2, w->broadphasePairs.data(), w->broadphasePairs.size() * sizeof(collider_pair)); }
+void orc_read_contacts(world* w, void* outContacts32, u32* outBodyPairs2, u32* outCollisionIndex)
+{
+	memcpy(outContacts32, w->contacts.data(), w->contacts.size() * sizeof(collision_contact));
+	memcpy(outBodyPairs2, w->contactBodyPairs.data(), w->contactBodyPairs.size() * sizeof(constraint_body_pair));
+	memcpy(outCollisionIndex, w->contactCollisionIndex.data(), w->contactCollisionIndex.size() * sizeof(u32));
+}
+void orc_read_collisions(world* w, u32* outPairs2, u8* outCounts)
+{
+	memcpy(outPairs2, w->collidingPairs.data(), w->collidingPairs.size() * sizeof(collider_pair));
+	memcpy(outCounts, w->contactCountPerCollision.data(), w->contactCountPerCollision.size());
+}
+// which: 0 = after solve, 1 = before solve (after gravity).  104 B records incl. the dummy at index N.
+void orc_read_rb_global(world* w, u32 which, void* out104)
+{
+	const std::vector<rigid_body_global_state>& v = which ? w->rbGlobalPreSolve : w->rbGlobal;
+	memcpy(out104, v.data(), v.size() * sizeof(rigid_body_global_state));
+}
+u32 orc_num_contact_slots(world* w) { return (u32)w->contactSlots.size(); }
+void orc_read_contact_slots(world* w, u32* out8) { memcpy(out8, w->contactSlots.data(), w->contactSlots.size() * sizeof(sched_slot)); }
+
+// ---- stage-level entry points for per-kernel parity tests -------------------------------------------
+// Narrowphase on caller-provided world-space colliders and ORDERED pairs (A,B as given, no reordering):
+// returns number of contacts; outCounts[numPairs] contact count per pair (0 = no collision).
+u32 orc_narrowphase_ordered(const void* colliders64, const u32* pairs2, u32 numPairs, void* outContacts32, u8* outCounts)
+{
+	const collider_union* cols = (const collider_union*)colliders64;
+	collision_contact* out = (collision_contact*)outContacts32;
+	u32 n = 0;
+	for (u32 i = 0; i < numPairs; ++i)
+	{
+		const collider_union& A = cols[pairs2[2 * i]];
+		const collider_union& B = cols[pairs2[2 * i + 1]];
+		contact_manifold m; m.numContacts = 0;
+		outCounts[i] = 0;
+		if (intersectColliders(A, B, m))
+		{
+			u32 fr = packFrictionRestitution(A, B);
+			outCounts[i] = (u8)m.numContacts;
+			for (u32 k = 0; k < m.numContacts; ++k)
+			{
+				out[n].point = m.contacts[k].point; out[n].penetrationDepth = m.contacts[k].penetrationDepth;
+				out[n].normal = m.collisionNormal; out[n].friction_restitution = fr;
+				++n;
+			}
+		}
+	}
+	return n;
+}
+// Scheduler on caller-provided body pairs; out8 must hold ceil(n/1)*8 u32 in the worst case.
+u32 orc_schedule(const u32* bodyPairs2, u32 n, u32 dummy, u32* out8)
+{
+	std::vector<sched_slot> slots;
+	scheduleConstraintsSIMD((const constraint_body_pair*)bodyPairs2, n, dummy, slots);
+	memcpy(out8, slots.data(), slots.size() * sizeof(sched_slot));
+	return (u32)slots.size();
+}
+// Contact init + `iterations` GS sweeps in the given order over caller-provided 104-byte body records (in/out).
+// outRows: 17 floats per contact {rA3 rB3 t3 mn mt bias lambdaN lambdaT ... } see oracle.py for the layout.
+void orc_solve_contacts(void* rb104, u32 numBodiesPlusDummy, const void* contacts32, const u32* bodyPairs2, u32 numContacts,
+	const u32* order, u32 orderLen, u32 iterations, float dt, float* outImpulses2)
+{
+	(void)numBodiesPlusDummy;
+	rigid_body_global_state* rbs = (rigid_body_global_state*)rb104;
+	const collision_contact* contacts = (const collision_contact*)contacts32;
+	const constraint_body_pair* pairs = (const constraint_body_pair*)bodyPairs2;
+	std::vector<collision_constraint> cons(numContacts);
+	for (u32 i = 0; i < numContacts; ++i) initializeCollisionConstraint(cons[i], rbs, contacts[i], pairs[i], dt);
+	for (u32 it = 0; it < iterations; ++it)
+	{
+		for (u32 k = 0; k < orderLen; ++k) { u32 i = order[k]; solveCollisionConstraint(cons[i], contacts[i], pairs[i], rbs); }
+	}
+	for (u32 i = 0; i < numContacts; ++i) { outImpulses2[2 * i] = cons[i].impulseInNormalDir; outImpulses2[2 * i + 1] = cons[i].impulseInTangentDir; }
+}
+
+void orc_stats(u32* out4) { out4[0] = g_gjkMaxItersSeen; out4[1] = g_epaMaxTriangles; out4[2] = g_epaMaxEdges; out4[3] = g_epaMaxBorder; }
+
+} // extern "C"

@@ -1,0 +1,58 @@
+"""Shared helpers for the GPU-vs-oracle parity tests.
+
+Whole-step parity works in "follow" mode: the HIP world steps first; the oracle then (1) computes its own world-space
+colliders, AABBs and sort-and-sweep pair SET, (2) runs its narrowphase on the device's ordered candidate pairs and (3) solves
+contacts manifold by manifold in the device's colour schedule (and joints in the device's joint order).  Within a colour no two
+manifolds share a dynamic body, so sequential execution on the CPU is the same Gauss-Seidel sweep the GPU ran in parallel.
+"""
+import numpy as np
+
+
+def pair_set(pairs):
+    p = np.asarray(pairs, np.uint64).reshape(-1, 2)
+    lo = np.minimum(p[:, 0], p[:, 1]); hi = np.maximum(p[:, 0], p[:, 1])
+    return np.unique((hi << np.uint64(32)) | lo)
+
+
+def quat_dist(a, b):
+    """max |q_a - (+/-)q_b| per body."""
+    d1 = np.abs(a - b).max(axis=1); d2 = np.abs(a + b).max(axis=1)
+    return np.minimum(d1, d2)
+
+
+def follow_step(gpu, orc_world, scene_dt, iterations=30, joint_counts=None):
+    """Step both worlds once; returns a dict of comparison metrics.  `orc_world.solver` must be SOLVER_CUSTOM."""
+    gpu.step_internal(scene_dt, iterations)
+    g_pairs = gpu.pairs()
+    slots, g_counts, g_contacts, g_bp = gpu.manifolds()
+    order, cs = gpu.schedule()
+    if joint_counts:
+        for t, n in joint_counts.items():
+            if n:
+                orc_world.set_joint_order(t, gpu.joint_order(t, n))
+    orc_world.set_follow(slots, order)
+    orc_world.step_internal(scene_dt, iterations)
+    o_pairs = orc_world.pairs()
+    o_counts = orc_world.slot_counts().astype(np.uint32)
+    out = {
+        "pairs_equal": np.array_equal(pair_set(g_pairs), pair_set(o_pairs)),
+        "num_pairs": len(g_pairs), "num_slots": len(slots), "num_manifolds": int((g_counts > 0).sum()),
+        "counts_equal": np.array_equal(g_counts, o_counts[:len(g_counts)]) and len(o_counts) == len(g_counts),
+        "num_colors": int((np.diff(cs[:65].astype(np.int64)) > 0).sum()),
+    }
+    if out["counts_equal"] and len(slots):
+        oc, obp, oci = orc_world.contacts()
+        mask = np.arange(4)[None, :] < g_counts[:, None]
+        gc = g_contacts[mask]
+        out["contact_point_err"] = float(np.abs(gc["point"] - oc["point"]).max()) if len(oc) else 0.0
+        out["contact_depth_err"] = float(np.abs(gc["depth"] - oc["depth"]).max()) if len(oc) else 0.0
+        out["contact_normal_err"] = float(np.abs(gc["normal"] - oc["normal"]).max()) if len(oc) else 0.0
+        out["contact_fr_equal"] = bool(np.array_equal(gc["friction_restitution"], oc["friction_restitution"])) if len(oc) else True
+        out["num_contacts"] = int(len(oc))
+    gt, ot = gpu.transforms(1), orc_world.transforms(1)
+    gv, ov = gpu.velocities(), orc_world.velocities()
+    out["pos_err"] = float(np.abs(gt[:, :3] - ot[:, :3]).max())
+    out["rot_err"] = float(quat_dist(gt[:, 3:], ot[:, 3:]).max())
+    out["vel_err"] = float(np.abs(gv - ov).max())
+    out["vel_scale"] = float(np.abs(ov).max())
+    return out
