@@ -32,10 +32,6 @@ MI_DEV bool aabbOverlap(float4 amin, float4 amax, float4 bmin, float4 bmax)
 	return true;
 }
 
-// counters layout (u32 indices into World::dCounters) — mirrors StepCounters
-enum { CTR_NUM_PAIRS = 0, CTR_NUM_VALID = 1, CTR_NUM_MANIFOLDS = 2, CTR_NUM_CONTACTS = 3, CTR_NUM_COLORS = 4, CTR_NUM_LARGE = 5, CTR_ROUNDS_LEFT = 6, CTR_OVERFLOW = 7,
-	CTR_COLOR_START = 8, CTR_BUCKET_START = 8 + MI_MAX_COLORS + 2, CTR_CELL_SIZE = CTR_BUCKET_START + 32, CTR_FIRST_LARGE = CTR_CELL_SIZE + 1 };
-
 // Largest extent among colliders that ride on a rigid body.  max() is order-independent, so the atomic is deterministic.
 __global__ void __launch_bounds__(256) k_max_extent(u32 nc, u32 nb, const ColliderRec* __restrict__ colWorld, const float4* __restrict__ aabbMin,
 	const float4* __restrict__ aabbMax, u32* __restrict__ counters)

@@ -5,10 +5,10 @@
 // Hull pairs and cylinder pairs are not built (SURVEY §8 a19 / out of the BASELINE configs).
 #include "world.h"
 #include <rocprim/rocprim.hpp>
+#include <algorithm>
 
 void prim_sort_pairs_u32_u64(World& w, const u32* kin, u32* kout, const u64* vin, u64* vout, u32 n, u32 bits);
 
-enum { CTR_NUM_PAIRS = 0, CTR_NUM_VALID = 1, CTR_BUCKET_START = 8 + MI_MAX_COLORS + 2 };
 #define KEY_INVALID 63u
 
 struct Man { V3 n; float4 p[4]; u32 count; };
@@ -43,8 +43,8 @@ __global__ void k_bucket_offsets(u32* __restrict__ counters, const u32* __restri
 	u32 n = counters[CTR_NUM_PAIRS];
 	u32 lo = 0, hi = n;
 	while (lo < hi) { u32 mid = (lo + hi) >> 1; if (keySorted[mid] < b) lo = mid + 1; else hi = mid; }
-	if (b < 32) counters[CTR_BUCKET_START + b] = lo; // keys >= 32 never occur below KEY_INVALID (max valid = 4*6+4 = 28)
-	if (b == KEY_INVALID) counters[CTR_NUM_VALID] = lo;
+	counters[CTR_BUCKET_START + b] = lo; // valid keys are <= 4*6+4 = 28; KEY_INVALID sorts last
+	if (b == KEY_INVALID) { counters[CTR_NUM_VALID] = lo; counters[CTR_EPA_COUNT] = 0; counters[CTR_NUM_ACTIVE] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -583,6 +583,8 @@ MI_DEV bool gjkCapsuleBox(const Capsule& c, const Box& b, GjkSimplex& sx)
 	return false;
 }
 
+#if 0 // thread-per-pair EPA with private scratch: 3.2 ms at config 3 (3.7 KB of scratch per lane, every access a dependent HBM
+      // round trip).  Kept for reference only; the wave-cooperative LDS version below replaces it.
 struct EpaTri { u8 a, b, c, eA, eB, eC; u8 active, pad; V3 normal; float dist; };
 struct EpaEdge { u8 a, b, tA, tB; };
 struct Epa
@@ -714,13 +716,157 @@ MI_DEV void epaCapsuleBox(const GjkSimplex& g, const Capsule& c, const Box& b, V
 	outNormal = tri.normal;
 	outDepth = tri.dist;
 }
+#endif
 
-MI_DEV bool capsuleBox(const Capsule& c, const Box& a, Man& m) // collision_narrow.cpp:705-769
+MI_DEV V3 barycentric(V3 a, V3 b, V3 c, V3 p) // math.cpp:1390-1408
 {
-	GjkSimplex sx;
-	if (!gjkCapsuleBox(c, a, sx)) return false;
-	V3 point, normal; float depth;
-	epaCapsuleBox(sx, c, a, point, normal, depth);
+	V3 v0 = b - a, v1 = c - a, v2 = p - a;
+	float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+	float denom = d00 * d11 - d01 * d01;
+	denom = (fabsf(denom) < MI_EPSILON) ? 1.f : denom;
+	float v = (d11 * d20 - d01 * d21) / denom;
+	float w = (d00 * d21 - d01 * d20) / denom;
+	float u = 1.0f - v - w;
+	return v3(u, v, w);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-cooperative EPA (collision_epa.h:96-168, collision_epa.cpp:5-239): ONE WAVE expands ONE polytope.  The polytope
+// (points, triangles, edges) lives in LDS (7.6 KB per wave); the per-iteration scans the serial algorithm does over all
+// triangles / edges are strided over the 64 lanes, the closest-triangle search is a shuffle min-reduction on (distance, index)
+// — the same "first strictly smaller" winner as the serial scan — and border edges are compacted in index order with
+// ballot + popcount, so indices, tie-breaks and therefore results are those of the serial reference algorithm.
+// Support points are recomputed redundantly by every lane (wave-uniform values, no LDS traffic).
+// ---------------------------------------------------------------------------------------------------------------
+struct EpaWave
+{
+	float pa[EPA_MAX_POINTS][3], pb[EPA_MAX_POINTS][3];          // support points on A and B; minkowski = a - b (bit-identical to the stored one)
+	float tnx[EPA_MAX_TRIANGLES], tny[EPA_MAX_TRIANGLES], tnz[EPA_MAX_TRIANGLES], tdist[EPA_MAX_TRIANGLES];
+	u32 ta[EPA_MAX_TRIANGLES], tb[EPA_MAX_TRIANGLES], tc[EPA_MAX_TRIANGLES], teA[EPA_MAX_TRIANGLES], teB[EPA_MAX_TRIANGLES], teC[EPA_MAX_TRIANGLES], tactive[EPA_MAX_TRIANGLES];
+	u32 ea[EPA_MAX_EDGES], eb[EPA_MAX_EDGES], etA[EPA_MAX_EDGES], etB[EPA_MAX_EDGES], refs[EPA_MAX_EDGES];
+	u32 border[EPA_MAX_BORDER], newEdgePerPoint[EPA_MAX_POINTS];
+};
+#define EPA_NONE32 0xFFFFu
+#define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier()
+
+__device__ __forceinline__ V3 epaMk(const EpaWave& e, u32 i) { return v3(e.pa[i][0], e.pa[i][1], e.pa[i][2]) - v3(e.pb[i][0], e.pb[i][1], e.pb[i][2]); }
+__device__ __forceinline__ void epaSetPoint(EpaWave& e, u32 i, const SupportPoint& p)
+{
+	e.pa[i][0] = p.a.x; e.pa[i][1] = p.a.y; e.pa[i][2] = p.a.z; e.pb[i][0] = p.b.x; e.pb[i][1] = p.b.y; e.pb[i][2] = p.b.z;
+}
+__device__ __forceinline__ void epaSetTri(EpaWave& e, u32 t, u32 a, u32 b, u32 c, u32 eA, u32 eB, u32 eC, V3 mka, V3 mkb, V3 mkc)
+{
+	V3 n = normalize(cross(mkb - mka, mkc - mka)); // getTriangleInfo (collision_epa.cpp:5-11)
+	e.tnx[t] = n.x; e.tny[t] = n.y; e.tnz[t] = n.z; e.tdist[t] = dot(n, mka);
+	e.ta[t] = a; e.tb[t] = b; e.tc[t] = c; e.teA[t] = eA; e.teB[t] = eB; e.teC[t] = eC; e.tactive[t] = 1;
+}
+
+// Runs on a full wave; every lane returns the same (point, normal, depth).
+__device__ void epaWaveCapsuleBox(EpaWave& e, u32 lane, const GjkSimplex& g, const Capsule& c, const Box& b, V3& outPoint, V3& outNormal, float& outDepth)
+{
+	u32 numTris = 4, numPoints = 4, numEdges = 6;
+	if (lane == 0)
+	{
+		epaSetPoint(e, 0, g.a); epaSetPoint(e, 1, g.b); epaSetPoint(e, 2, g.c); epaSetPoint(e, 3, g.d);
+		epaSetTri(e, 0, 0, 1, 3, 4, 3, 0, g.a.mk, g.b.mk, g.d.mk);
+		epaSetTri(e, 1, 1, 2, 3, 5, 4, 1, g.b.mk, g.c.mk, g.d.mk);
+		epaSetTri(e, 2, 2, 0, 3, 3, 5, 2, g.c.mk, g.a.mk, g.d.mk);
+		epaSetTri(e, 3, 0, 2, 1, 1, 0, 2, g.a.mk, g.c.mk, g.b.mk);
+		const u32 E[6][4] = { { 0, 1, 0, 3 }, { 1, 2, 1, 3 }, { 2, 0, 2, 3 }, { 0, 3, 2, 0 }, { 1, 3, 0, 1 }, { 2, 3, 1, 2 } };
+		for (u32 i = 0; i < 6; ++i) { e.ea[i] = E[i][0]; e.eb[i] = E[i][1]; e.etA[i] = E[i][2]; e.etB[i] = E[i][3]; }
+	}
+	WAVE_SYNC();
+
+	u32 closest = 0;
+	for (u32 it = 0; it < 20; ++it)
+	{
+		// findTriangleClosestToOrigin (collision_epa.cpp:89-109): lowest index among the minimal distances
+		float bd = MI_FLT_MAX; u32 bi = 0xFFFFFFFFu;
+		for (u32 t = lane; t < numTris; t += 64) { if (e.tactive[t]) { float d = e.tdist[t]; if (d < bd) { bd = d; bi = t; } } }
+		for (int o = 32; o > 0; o >>= 1)
+		{
+			float od = __shfl_xor(bd, o); u32 oi = __shfl_xor(bi, o);
+			if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+		}
+		closest = bi;
+		if (closest == 0xFFFFFFFFu) { closest = 0; break; }
+		V3 tn = v3(e.tnx[closest], e.tny[closest], e.tnz[closest]);
+		SupportPoint np = supportCB(c, b, tn);
+		float dd = dot(np.mk, tn);
+		if (dd - e.tdist[closest] < 0.01f) break;
+
+		// addNewPointAndUpdate (collision_epa.cpp:111-239)
+		for (u32 i = lane; i < numEdges; i += 64) e.refs[i] = 0;
+		if (lane < EPA_MAX_POINTS) e.newEdgePerPoint[lane] = 0;
+		WAVE_SYNC();
+		for (u32 t = lane; t < numTris; t += 64)
+		{
+			if (e.tactive[t])
+			{
+				float d = dot(v3(e.tnx[t], e.tny[t], e.tnz[t]), np.mk - epaMk(e, e.ta[t]));
+				if (d > 0.f) { atomicAdd(&e.refs[e.teA[t]], 1u); atomicAdd(&e.refs[e.teB[t]], 1u); atomicAdd(&e.refs[e.teC[t]], 1u); e.tactive[t] = 0; }
+			}
+		}
+		WAVE_SYNC();
+		u32 nBorder = 0;
+		for (u32 base = 0; base < numEdges; base += 64) // border edges in edge-index order
+		{
+			u32 i = base + lane;
+			bool flag = i < numEdges && e.refs[i] == 1;
+			u64 mask = __ballot(flag);
+			u32 pos = nBorder + __popcll(mask & ((1ull << lane) - 1ull));
+			if (flag && pos < EPA_MAX_BORDER) e.border[pos] = i;
+			nBorder += __popcll(mask);
+		}
+		if (nBorder > EPA_MAX_BORDER) break;                                     // "out of memory" exits, as the serial code's pushes would hit them
+		if (numPoints >= EPA_MAX_POINTS) break;
+		if (numEdges + nBorder > EPA_MAX_EDGES || numTris + nBorder > EPA_MAX_TRIANGLES) break;
+		u32 newPoint = numPoints++;
+		if (lane == 0) epaSetPoint(e, newPoint, np);
+		WAVE_SYNC();
+		u32 triOffset = numTris;
+		if (lane < nBorder)
+		{
+			u32 ei = e.border[lane];
+			u32 ea = e.ea[ei], eb = e.eb[ei], tA = e.etA[ei], tB = e.etB[ei];
+			bool triAActive = e.tactive[tA] != 0, triBActive = e.tactive[tB] != 0;
+			u32 ptc = triBActive ? ea : eb;
+			u32 triIndex = numTris + lane, newEdge = numEdges + lane;
+			e.ea[newEdge] = ptc; e.eb[newEdge] = newPoint; e.etA[newEdge] = EPA_NONE32; e.etB[newEdge] = triIndex;
+			atomicMax(&e.newEdgePerPoint[ptc], newEdge);                      // serial code: last writer (= highest index) wins
+			u32 bI = ptc, cI = triBActive ? eb : ea;
+			epaSetTri(e, triIndex, newPoint, bI, cI, ei, EPA_NONE32, newEdge, np.mk, epaMk(e, bI), epaMk(e, cI));
+			if (triAActive) e.etB[ei] = triIndex; else e.etA[ei] = triIndex;
+		}
+		numEdges += nBorder; numTris += nBorder;
+		WAVE_SYNC();
+		if (lane < nBorder) // fix up the indices left open above
+		{
+			u32 ei = e.border[lane];
+			bool triBNew = e.etB[ei] >= triOffset;
+			u32 ptc = triBNew ? e.ea[ei] : e.eb[ei];
+			u32 other = e.newEdgePerPoint[ptc];
+			u32 triIndex = lane + triOffset;
+			e.teB[triIndex] = other;
+			e.etA[other] = triIndex;
+		}
+		WAVE_SYNC();
+	}
+	V3 tn = v3(e.tnx[closest], e.tny[closest], e.tnz[closest]);
+	float tdist = e.tdist[closest];
+	u32 ia = e.ta[closest], ib = e.tb[closest], ic = e.tc[closest];
+	V3 bary = barycentric(epaMk(e, ia), epaMk(e, ib), epaMk(e, ic), tn * tdist);
+	V3 pointA = bary.x * v3(e.pa[ia][0], e.pa[ia][1], e.pa[ia][2]) + bary.y * v3(e.pa[ib][0], e.pa[ib][1], e.pa[ib][2]) + bary.z * v3(e.pa[ic][0], e.pa[ic][1], e.pa[ic][2]);
+	V3 pointB = bary.x * v3(e.pb[ia][0], e.pb[ia][1], e.pb[ia][2]) + bary.y * v3(e.pb[ib][0], e.pb[ib][1], e.pb[ib][2]) + bary.z * v3(e.pb[ic][0], e.pb[ic][1], e.pb[ic][2]);
+	outPoint = 0.5f * (pointA + pointB);
+	outNormal = tn;
+	outDepth = tdist;
+	WAVE_SYNC(); // the next instance reuses this LDS block
+}
+
+// Everything of intersection(capsule, aabb) after EPA — collision_narrow.cpp:723-768
+MI_DEV void capsuleBoxFinish(V3 point, V3 normal, float depth, const Capsule& c, const Box& a, Man& m)
+{
 	m.n = normal; m.count = 1;
 	m.p[0] = make_float4(point.x, point.y, point.z, depth);
 	if (fabsf(normal.x) > 0.99f || fabsf(normal.y) > 0.99f || fabsf(normal.z) > 0.99f)
@@ -743,23 +889,16 @@ MI_DEV bool capsuleBox(const Capsule& c, const Box& a, Man& m) // collision_narr
 			clipPointsAndBuildContact(polygon, clipPlanes, referencePlane, m);
 		}
 	}
-	return true;
 }
-MI_DEV bool capsuleObb(const Capsule& c, const Obb& o, Man& m) // :771-790
+// intersection(capsule, obb) works in the box's frame (:771-790): operands for the shared capsule-vs-aabb code.
+MI_DEV void capsuleBoxOperands(u32 key, const ColliderRec& A, const ColliderRec& B, Capsule& c, Box& box, Obb& o)
 {
-	Box aabb; aabb.lo = o.c - o.r; aabb.hi = o.c + o.r;
+	c = asCapsule(A);
+	if (key == 9) { box = asBox(B); return; }
+	o = asObb(B);
+	box.lo = o.c - o.r; box.hi = o.c + o.r;
 	Capsule c_; c_.a = conjugate(o.q) * (c.a - o.c) + o.c; c_.b = conjugate(o.q) * (c.b - o.c) + o.c; c_.r = c.r;
-	if (capsuleBox(c_, aabb, m))
-	{
-		m.n = o.q * m.n;
-		for (u32 i = 0; i < m.count; ++i)
-		{
-			V3 pt = o.q * (v3f4(m.p[i]) - o.c) + o.c;
-			m.p[i] = make_float4(pt.x, pt.y, pt.z, m.p[i].w);
-		}
-		return true;
-	}
-	return false;
+	c = c_;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -778,19 +917,21 @@ MI_DEV void writeManifold(ManifoldRec* __restrict__ out, u32 slot, const Man& m,
 	out[slot] = r;
 }
 
-enum { GROUP_CLOSED = 0, GROUP_BOX = 1, GROUP_GJK = 2 };
+enum { GROUP_CLOSED = 0, GROUP_BOX = 1 };
 
+// GROUP_CLOSED scans all valid slots and skips foreign buckets (its buckets are scattered over the key space);
+// GROUP_BOX covers the contiguous slot range of keys 22..28 (aabb-obb, obb-obb; keys 23..27 are hull pairs and never occur).
 template <int GROUP>
 __global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
 	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds)
 {
 	u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (GROUP == GROUP_BOX) { slot += counters[CTR_BUCKET_START + 22]; if (slot >= counters[CTR_BUCKET_START + 29]) return; }
 	if (slot >= counters[CTR_NUM_VALID]) return;
 	u32 key = keySorted[slot];
 	bool mine;
 	if (GROUP == GROUP_CLOSED) mine = (key == 0 || key == 1 || key == 3 || key == 4 || key == 7 || key == 21);
-	else if (GROUP == GROUP_BOX) mine = (key == 22 || key == 28);
-	else mine = (key == 9 || key == 10);
+	else mine = (key == 22 || key == 28);
 	if (!mine) return;
 	u64 packed = pairSorted[slot];
 	u32 ia = (u32)packed, ib = (u32)(packed >> 32);
@@ -809,19 +950,88 @@ __global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(con
 			case 21: hit = boxBoxAxisAligned(asBox(A), asBox(B), m); break;
 		}
 	}
-	else if (GROUP == GROUP_BOX)
+	else
 	{
 		Obb oa;
 		if (key == 22) { Box b = asBox(A); oa.q = q4(0.f, 0.f, 0.f, 1.f); oa.c = boxCenter(b); oa.r = boxRadius(b); } // aabb -> obb (:1142-1148)
 		else oa = asObb(A);
 		hit = obbObb(oa, asObb(B), m);
 	}
-	else
-	{
-		if (key == 9) hit = capsuleBox(asCapsule(A), asBox(B), m);
-		else hit = capsuleObb(asCapsule(A), asObb(B), m);
-	}
 	writeManifold(manifolds, slot, m, hit, A, B, slot);
+}
+
+// Capsule vs box, phase 1: the GJK boolean test over the contiguous slot range of keys 9..10 (registers only).  Misses write
+// their empty manifold; hits append (slot, simplex) to the EPA work list so that phase 2 runs with dense waves — the
+// expanding polytope needs ~3.7 KB of private scratch per lane and 20 serial iterations, which must not idle behind misses.
+__global__ void __launch_bounds__(256) k_gjk(u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
+	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, u32* __restrict__ epaList, float4* __restrict__ gjkSimplex)
+{
+	u32 slot = counters[CTR_BUCKET_START + 9] + blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= counters[CTR_BUCKET_START + 11]) return;
+	u32 key = keySorted[slot];
+	u64 packed = pairSorted[slot];
+	ColliderRec A = colWorld[(u32)packed], B = colWorld[(u32)(packed >> 32)];
+	Capsule c; Box box; Obb o;
+	capsuleBoxOperands(key, A, B, c, box, o);
+	GjkSimplex sx;
+	if (!gjkCapsuleBox(c, box, sx))
+	{
+		Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
+		writeManifold(manifolds, slot, m, false, A, B, slot);
+		return;
+	}
+	u32 j = atomicAdd(&counters[CTR_EPA_COUNT], 1u); // order of the work list does not affect any result
+	epaList[j] = slot;
+	float4* S = gjkSimplex + (size_t)j * 9;
+	const SupportPoint* P[4] = { &sx.a, &sx.b, &sx.c, &sx.d };
+	float f[36];
+	for (u32 i = 0; i < 4; ++i) { f[9 * i] = P[i]->a.x; f[9 * i + 1] = P[i]->a.y; f[9 * i + 2] = P[i]->a.z; f[9 * i + 3] = P[i]->b.x; f[9 * i + 4] = P[i]->b.y; f[9 * i + 5] = P[i]->b.z;
+		f[9 * i + 6] = P[i]->mk.x; f[9 * i + 7] = P[i]->mk.y; f[9 * i + 8] = P[i]->mk.z; }
+	for (u32 i = 0; i < 9; ++i) S[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+}
+
+// Phase 2: EPA (one wave per hit, polytope in LDS) + face clipping (lane 0) for every GJK hit.  Waves stride over the work list.
+#define EPA_WAVES_PER_BLOCK 4
+__global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) k_epa(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
+	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, const u32* __restrict__ epaList, const float4* __restrict__ gjkSimplex)
+{
+	__shared__ EpaWave shared[EPA_WAVES_PER_BLOCK];
+	u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	EpaWave& e = shared[wave];
+	u32 numHits = counters[CTR_EPA_COUNT];
+	u32 stride = gridDim.x * EPA_WAVES_PER_BLOCK;
+	for (u32 j = blockIdx.x * EPA_WAVES_PER_BLOCK + wave; j < numHits; j += stride)
+	{
+		u32 slot = epaList[j];
+		u32 key = keySorted[slot];
+		u64 packed = pairSorted[slot];
+		ColliderRec A = colWorld[(u32)packed], B = colWorld[(u32)(packed >> 32)];
+		Capsule c; Box box; Obb o;
+		capsuleBoxOperands(key, A, B, c, box, o);
+		const float4* S = gjkSimplex + (size_t)j * 9;
+		float f[36];
+		for (u32 i = 0; i < 9; ++i) { float4 v = S[i]; f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w; }
+		GjkSimplex sx; sx.numPoints = 4;
+		SupportPoint* P[4] = { &sx.a, &sx.b, &sx.c, &sx.d };
+		for (u32 i = 0; i < 4; ++i) { P[i]->a = v3(f[9 * i], f[9 * i + 1], f[9 * i + 2]); P[i]->b = v3(f[9 * i + 3], f[9 * i + 4], f[9 * i + 5]); P[i]->mk = v3(f[9 * i + 6], f[9 * i + 7], f[9 * i + 8]); }
+		V3 point, normal; float depth;
+		epaWaveCapsuleBox(e, lane, sx, c, box, point, normal, depth);
+		if (lane == 0)
+		{
+			Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
+			capsuleBoxFinish(point, normal, depth, c, box, m);
+			if (key == 10) // back to world space (:779-787)
+			{
+				m.n = o.q * m.n;
+				for (u32 i = 0; i < m.count; ++i)
+				{
+					V3 pt = o.q * (v3f4(m.p[i]) - o.c) + o.c;
+					m.p[i] = make_float4(pt.x, pt.y, pt.z, m.p[i].w);
+				}
+			}
+			writeManifold(manifolds, slot, m, true, A, B, slot);
+		}
+	}
 }
 
 void launch_narrowphase(World& w, u32 numPairs)
@@ -832,7 +1042,10 @@ void launch_narrowphase(World& w, u32 numPairs)
 	// sort (bucket key, packed pair): unsorted packed pairs live in the upper half of pairsSorted, sorted ones in the lower half
 	prim_sort_pairs_u32_u64(w, w.pairKey.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p + numPairs, (u64*)w.pairsSorted.p, numPairs, 6);
 	hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_CLOSED>), grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p, w.colWorld.p, w.manifolds.p);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_BOX>), dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p, w.colWorld.p, w.manifolds.p);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_GJK>), dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p, w.colWorld.p, w.manifolds.p);
+	const u64* sortedPairs = (const u64*)w.pairsSorted.p;
+	hipLaunchKernelGGL(k_gjk, grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_CLOSED>), grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_BOX>), dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p);
+	u32 epaBlocks = std::min<u32>((numPairs + EPA_WAVES_PER_BLOCK - 1) / EPA_WAVES_PER_BLOCK, 256u * 5u); // 5 blocks of 4 waves fit a CU's LDS
+	hipLaunchKernelGGL(k_epa, dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p);
 }

@@ -6,49 +6,54 @@
 // both bodies' velocities in registers across its contacts and touches each body once per sweep (2 x 32-B gather + scatter), so
 // box stacks need 4x fewer colours and body traffic than per-contact colouring.  Manifolds of one colour share no dynamic body
 // => a colour is one fully parallel launch; colours run in order.  Rows are SoA float4 planes indexed by the manifold's position
-// in (colour, contact-count) order, so every wave reads 1 KiB contiguous per plane (16 B/lane) and lanes that still have a k-th
-// contact are contiguous.  No atomics on velocities, no CAS loops; the static dummy body (index numBodies) is never written.
+// in (colour, contact-count) order, so every wave reads 1 KiB contiguous per plane (16 B/lane), lanes that still have a k-th
+// contact are contiguous, and a lane knows its contact count from its slot index alone — every row load of a sweep is issued
+// before the first dependent gather returns.  No atomics on velocities; the static dummy body (index numBodies) is never written.
 #include "world.h"
 #include <rocprim/rocprim.hpp>
 
 void prim_sort_pairs_u32(World& w, const u32* kin, u32* kout, const u32* vin, u32* vout, u32 n, u32 bits);
 
-enum { CTR_NUM_PAIRS = 0, CTR_NUM_VALID = 1, CTR_NUM_MANIFOLDS = 2, CTR_NUM_CONTACTS = 3, CTR_NUM_COLORS = 4, CTR_NUM_LARGE = 5, CTR_ROUNDS_LEFT = 6, CTR_OVERFLOW = 7,
-	CTR_COLOR_START = 8 };
-
 #define UNCOLORED 0xFFFFFFFFu
-#define INACTIVE 0xFFFFFFFEu
 #define KEY_INACTIVE 0x3FFu
 
 MI_DEV u32 hash32(u32 x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
-// later rounds and (pseudo-random) higher priority => smaller key; the manifold index makes keys unique
-MI_DEV u64 claimKey(u32 round, u32 m) { return ((u64)(0xFFFFu - round) << 48) | ((u64)(hash32(m * 2654435761u + round) & 0xFFFFFFu) << 24) | (u64)(m & 0xFFFFFFu); }
+// later rounds and (pseudo-random) higher priority => smaller key; the manifold slot makes keys unique and order-independent
+MI_DEV u64 claimKey(u32 round, u32 slot) { return ((u64)(0xFFFFu - round) << 48) | ((u64)(hash32(slot * 2654435761u + round) & 0xFFFFFFu) << 24) | (u64)(slot & 0xFFFFFFu); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Active list: manifolds with at least one contact, appended with one wave-aggregated atomic per wave.  The list order is
+// arbitrary; nothing downstream depends on it (claims are keyed by slot, a colour's members are mutually independent).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_active_list(u32* __restrict__ counters, const ManifoldRec* __restrict__ manifolds, uint4* __restrict__ actIds, u32* __restrict__ mColor)
+{
+	u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m >= counters[CTR_NUM_VALID]) return;
+	uint4 ids = manifolds[m].ids;
+	if (!ids.z) return;
+	u32 j = atomicAdd(&counters[CTR_NUM_ACTIVE], 1u);
+	actIds[j] = make_uint4(ids.x, ids.y, ids.z, m);
+	mColor[j] = UNCOLORED;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Colouring: Luby-style rounds.  Round r: every uncoloured manifold checks whether it won BOTH of its bodies in round r-1
 // (then takes the lowest colour free at both bodies); otherwise it bids again.  Bids are 64-bit atomicMin into a per-body
 // slot, double-buffered by round parity; min() is order-independent, so the colouring is deterministic.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_color_begin(const u32* __restrict__ counters, const ManifoldRec* __restrict__ manifolds, u32* __restrict__ mColor)
-{
-	u32 m = blockIdx.x * blockDim.x + threadIdx.x;
-	if (m >= counters[CTR_NUM_VALID]) return;
-	mColor[m] = manifolds[m].ids.z ? UNCOLORED : INACTIVE;
-}
-
-__global__ void __launch_bounds__(256) k_color_round(u32* __restrict__ counters, u32 nb, u32 round, u32 lastRound, const ManifoldRec* __restrict__ manifolds,
+__global__ void __launch_bounds__(256) k_color_round(u32* __restrict__ counters, u32 nb, u32 round, u32 lastRound, const uint4* __restrict__ actIds,
 	u32* __restrict__ mColor, u64* __restrict__ bodyMask, u64* __restrict__ claim)
 {
-	u32 m = blockIdx.x * blockDim.x + threadIdx.x;
-	if (m >= counters[CTR_NUM_VALID]) return;
-	if (mColor[m] != UNCOLORED) return;
-	uint4 ids = manifolds[m].ids;
-	u32 a = ids.x, b = ids.y;
+	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= counters[CTR_NUM_ACTIVE]) return;
+	if (mColor[j] != UNCOLORED) return;
+	uint4 ids = actIds[j];
+	u32 a = ids.x, b = ids.y, slot = ids.w;
 	bool da = a < nb, db = b < nb;
 	if (round > 0)
 	{
 		const u64* prev = claim + (size_t)((round - 1) & 1) * nb;
-		u64 key = claimKey(round - 1, m);
+		u64 key = claimKey(round - 1, slot);
 		bool won = (!da || prev[a] == key) && (!db || prev[b] == key);
 		if (won)
 		{
@@ -62,57 +67,57 @@ __global__ void __launch_bounds__(256) k_color_round(u32* __restrict__ counters,
 				if (da) bodyMask[a] |= (1ull << c);
 				if (db) bodyMask[b] |= (1ull << c);
 			}
-			mColor[m] = c;
-			atomicMax(&counters[CTR_ROUNDS_LEFT], round); // last round that coloured anything (drives the adaptive round count)
+			mColor[j] = c;
+			atomicMax(&counters[CTR_LAST_ROUND], round); // drives the adaptive round budget
 			return;
 		}
 	}
-	if (round == lastRound) // out of rounds: serial bucket keeps the step correct; the host raises the round budget
+	if (round == lastRound) // out of rounds: the serial bucket keeps the step correct; the host raises the budget
 	{
-		mColor[m] = MI_SERIAL_COLOR;
+		mColor[j] = MI_SERIAL_COLOR;
 		atomicAdd(&counters[CTR_OVERFLOW], 1u);
 		return;
 	}
 	u64* cur = claim + (size_t)(round & 1) * nb;
-	u64 key = claimKey(round, m);
+	u64 key = claimKey(round, slot);
 	if (da) atomicMin((unsigned long long*)&cur[a], (unsigned long long)key);
 	if (db) atomicMin((unsigned long long*)&cur[b], (unsigned long long)key);
 }
 
-__global__ void __launch_bounds__(256) k_color_keys(const u32* __restrict__ counters, u32 numPairs, const ManifoldRec* __restrict__ manifolds, const u32* __restrict__ mColor,
+__global__ void __launch_bounds__(256) k_color_keys(const u32* __restrict__ counters, u32 numPairs, const uint4* __restrict__ actIds, const u32* __restrict__ mColor,
 	u32* __restrict__ mKey, u32* __restrict__ mIdx)
 {
-	u32 m = blockIdx.x * blockDim.x + threadIdx.x;
-	if (m >= numPairs) return;
+	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= numPairs) return;
 	u32 key = KEY_INACTIVE;
-	if (m < counters[CTR_NUM_VALID])
+	if (j < counters[CTR_NUM_ACTIVE])
 	{
-		u32 c = mColor[m];
-		if (c <= MI_SERIAL_COLOR) key = c * 4 + (4 - manifolds[m].ids.z);
+		u32 c = mColor[j];
+		if (c <= MI_SERIAL_COLOR) key = c * 4 + (4 - actIds[j].z);
 	}
-	mKey[m] = key;
-	mIdx[m] = m;
+	mKey[j] = key;
+	mIdx[j] = j;
 }
 
-__global__ void k_color_offsets(u32* __restrict__ counters, u32 numPairs, const u32* __restrict__ keySorted)
+__global__ void __launch_bounds__(512) k_color_offsets(u32* __restrict__ counters, u32 numPairs, const u32* __restrict__ keySorted)
 {
-	u32 c = threadIdx.x; // 0 .. MI_MAX_COLORS+1 (start of colour c; c = 65 -> end of the serial bucket = numManifolds)
-	__shared__ u32 starts[MI_MAX_COLORS + 2];
-	if (c < MI_MAX_COLORS + 2)
+	u32 k = threadIdx.x; // schedule key colour*4 + (4-count); k = MI_NUM_SCHEDULE_KEYS -> end of schedule = numManifolds
+	__shared__ u32 starts[MI_NUM_SCHEDULE_KEYS + 1];
+	if (k <= MI_NUM_SCHEDULE_KEYS)
 	{
-		u32 target = (c <= MI_SERIAL_COLOR) ? c * 4 : KEY_INACTIVE;
+		u32 target = (k < MI_NUM_SCHEDULE_KEYS) ? k : KEY_INACTIVE;
 		u32 lo = 0, hi = numPairs;
 		while (lo < hi) { u32 mid = (lo + hi) >> 1; if (keySorted[mid] < target) lo = mid + 1; else hi = mid; }
-		starts[c] = lo;
-		counters[CTR_COLOR_START + c] = lo;
+		starts[k] = lo;
+		counters[CTR_KEY_START + k] = lo;
 	}
 	__syncthreads();
-	if (c == 0)
+	if (k == 0)
 	{
 		u32 n = 0;
-		for (u32 i = 0; i < MI_MAX_COLORS; ++i) if (starts[i + 1] > starts[i]) n = i + 1;
+		for (u32 c = 0; c < MI_MAX_COLORS; ++c) if (starts[(c + 1) * 4] > starts[c * 4]) n = c + 1;
 		counters[CTR_NUM_COLORS] = n;
-		counters[CTR_NUM_MANIFOLDS] = starts[MI_MAX_COLORS + 1];
+		counters[CTR_NUM_MANIFOLDS] = starts[MI_NUM_SCHEDULE_KEYS];
 	}
 }
 
@@ -123,14 +128,17 @@ void launch_coloring(World& w, u32 numPairs)
 	u32 nb = w.nb;
 	MI_CHECK(hipMemsetAsync(w.bodyMask.p, 0, sizeof(u64) * (nb + 1), w.stream));
 	MI_CHECK(hipMemsetAsync(w.claim.p, 0xFF, sizeof(u64) * 2 * (nb + 1), w.stream));
-	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_ROUNDS_LEFT, 0, 2 * sizeof(u32), w.stream));
-	hipLaunchKernelGGL(k_color_begin, grid, block, 0, w.stream, w.dCounters.p, w.manifolds.p, w.mColor.p);
+	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_LAST_ROUND, 0, 2 * sizeof(u32), w.stream));
+	hipLaunchKernelGGL(k_active_list, grid, block, 0, w.stream, w.dCounters.p, w.manifolds.p, w.actIds.p, w.mColor.p);
+	// the active count is not known on the host yet: size the round launches by last step's count (+25 %), never above numPairs
+	u32 est = w.lastNumManifolds ? std::min<u32>(numPairs, w.lastNumManifolds + w.lastNumManifolds / 4 + 1024) : numPairs;
+	dim3 rgrid((est + 255) / 256);
 	u32 rounds = w.coloringRounds;
 	for (u32 r = 0; r <= rounds; ++r)
-		hipLaunchKernelGGL(k_color_round, grid, block, 0, w.stream, w.dCounters.p, nb, r, rounds, w.manifolds.p, w.mColor.p, w.bodyMask.p, w.claim.p);
-	hipLaunchKernelGGL(k_color_keys, grid, block, 0, w.stream, w.dCounters.p, numPairs, w.manifolds.p, w.mColor.p, w.mKey.p, w.mIdx.p);
+		hipLaunchKernelGGL(k_color_round, (r == rounds) ? grid : rgrid, block, 0, w.stream, w.dCounters.p, nb, r, rounds, w.actIds.p, w.mColor.p, w.bodyMask.p, w.claim.p);
+	hipLaunchKernelGGL(k_color_keys, grid, block, 0, w.stream, w.dCounters.p, numPairs, w.actIds.p, w.mColor.p, w.mKey.p, w.mIdx.p);
 	prim_sort_pairs_u32(w, w.mKey.p, w.mKeySorted.p, w.mIdx.p, w.mOrder.p, numPairs, 10);
-	hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(128), 0, w.stream, w.dCounters.p, numPairs, w.mKeySorted.p);
+	hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(512), 0, w.stream, w.dCounters.p, numPairs, w.mKeySorted.p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -145,13 +153,13 @@ MI_DEV M3 loadInvI(const float4* __restrict__ invIw, u32 i)
 	return I;
 }
 
-__global__ void __launch_bounds__(256) k_contact_init(const u32* __restrict__ counters, float dt, size_t rowCap, const u32* __restrict__ mOrder,
+__global__ void __launch_bounds__(256) k_contact_init(const u32* __restrict__ counters, float dt, size_t rowCap, const u32* __restrict__ mOrder, const uint4* __restrict__ actIds,
 	const ManifoldRec* __restrict__ manifolds, const float4* __restrict__ cog, const float4* __restrict__ invIw, const float4* __restrict__ vel,
 	float4* __restrict__ rowPlanes, float4* __restrict__ rowShared, float2* __restrict__ rowLambda, uint4* __restrict__ rowIds)
 {
 	u32 s = blockIdx.x * blockDim.x + threadIdx.x;
 	if (s >= counters[CTR_NUM_MANIFOLDS]) return;
-	u32 m = mOrder[s];
+	u32 m = actIds[mOrder[s]].w;
 	ManifoldRec man = manifolds[m];
 	u32 a = man.ids.x, b = man.ids.y, count = man.ids.z;
 	float4 ca = cog[a], cb = cog[b];
@@ -209,90 +217,116 @@ __global__ void __launch_bounds__(256) k_contact_init(const u32* __restrict__ co
 void launch_contact_init(World& w, u32 numPairs, float dt)
 {
 	if (!numPairs) return;
-	hipLaunchKernelGGL(k_contact_init, dim3((numPairs + 255) / 256), dim3(256), 0, w.stream, w.dCounters.p, dt, w.rowCap, w.mOrder.p, w.manifolds.p,
+	hipLaunchKernelGGL(k_contact_init, dim3((numPairs + 255) / 256), dim3(256), 0, w.stream, w.dCounters.p, dt, w.rowCap, w.mOrder.p, w.actIds.p, w.manifolds.p,
 		w.cog.p, w.invIw.p, w.vel.p, w.rowPlanes.p, w.rowShared.p, w.rowLambda.p, w.rowIds.p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K11: the sweep.  One lane = one manifold; friction row then normal row per contact (A.3 of SURVEY).
 // ---------------------------------------------------------------------------------------------------------------
-MI_DEV void solveManifold(u32 s, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes, const float4* __restrict__ rowShared, float2* __restrict__ rowLambda,
+struct ContactRow { float4 p0, p1, p2, p3, p4, p5; float2 lam; };
+
+MI_DEV void loadRow(ContactRow& r, u32 k, u32 s, size_t rowCap, const float4* __restrict__ rowPlanes, const float2* __restrict__ rowLambda)
+{
+	const float4* P = rowPlanes + (size_t)(k * MI_ROW_PLANES) * rowCap + s;
+	r.p0 = P[0]; r.p1 = P[rowCap]; r.p2 = P[2 * rowCap]; r.p3 = P[3 * rowCap]; r.p4 = P[4 * rowCap]; r.p5 = P[5 * rowCap];
+	r.lam = rowLambda[(size_t)k * rowCap + s];
+}
+
+MI_DEV void solveRow(ContactRow& r, V3 n, float friction, float invMassA, float invMassB, V3& vA, V3& wA, V3& vB, V3& wB)
+{
+	V3 rA = v3(r.p0.x, r.p0.y, r.p0.z), rB = v3(r.p0.w, r.p1.x, r.p1.y), t = v3(r.p1.z, r.p1.w, r.p2.x);
+	V3 JnA = v3(r.p2.y, r.p2.z, r.p2.w), JtA = v3(r.p3.x, r.p3.y, r.p3.z), JnB = v3(r.p3.w, r.p4.x, r.p4.y), JtB = v3(r.p4.z, r.p4.w, r.p5.x);
+	float mN = r.p5.y, mT = r.p5.z, bias = r.p5.w;
+	float impulseN = r.lam.x, impulseT = r.lam.y;
+	{ // tangent (constraints.cpp:3404-3424)
+		V3 rel = (vB + cross(wB, rB)) - (vA + cross(wA, rA));
+		float vt = dot(rel, t);
+		float lambda = -mT * vt;
+		float maxFriction = friction * impulseN;
+		float newImpulse = clampf(impulseT + lambda, -maxFriction, maxFriction);
+		lambda = newImpulse - impulseT;
+		impulseT = newImpulse;
+		V3 Pv = lambda * t;
+		vA -= invMassA * Pv; wA -= JtA * lambda;
+		vB += invMassB * Pv; wB += JtB * lambda;
+	}
+	{ // normal (constraints.cpp:3426-3442)
+		V3 rel = (vB + cross(wB, rB)) - (vA + cross(wA, rA));
+		float vn = dot(rel, n);
+		float lambda = -mN * (vn - bias);
+		float impulse = fmaxf(impulseN + lambda, 0.f);
+		lambda = impulse - impulseN;
+		impulseN = impulse;
+		V3 Pv = lambda * n;
+		vA -= invMassA * Pv; wA -= JnA * lambda;
+		vB += invMassB * Pv; wB += JnB * lambda;
+	}
+	r.lam = make_float2(impulseN, impulseT);
+}
+
+// `count` comes from the slot index (the schedule is sorted by contact count inside a colour), so all row loads are issued
+// up front, in parallel with the id -> body gather chain.
+MI_DEV void solveManifold(u32 s, u32 count, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes, const float4* __restrict__ rowShared, float2* __restrict__ rowLambda,
 	const uint4* __restrict__ rowIds, float4* __restrict__ vel)
 {
 	uint4 ids = rowIds[s];
-	u32 a = ids.x, b = ids.y, count = ids.z;
 	float4 sh = rowShared[s];
+	ContactRow r0, r1, r2, r3;
+	loadRow(r0, 0, s, rowCap, rowPlanes, rowLambda);
+	if (count > 1) loadRow(r1, 1, s, rowCap, rowPlanes, rowLambda);
+	if (count > 2) loadRow(r2, 2, s, rowCap, rowPlanes, rowLambda);
+	if (count > 3) loadRow(r3, 3, s, rowCap, rowPlanes, rowLambda);
+	u32 a = ids.x, b = ids.y;
+	float4 la = vel[2 * a], aa = vel[2 * a + 1], lb = vel[2 * b], ab = vel[2 * b + 1];
 	V3 n = v3(sh.x, sh.y, sh.z);
 	float friction = sh.w;
-	float4 la = vel[2 * a], aa = vel[2 * a + 1], lb = vel[2 * b], ab = vel[2 * b + 1];
 	V3 vA = v3f4(la), wA = v3f4(aa), vB = v3f4(lb), wB = v3f4(ab);
 	float invMassA = la.w, invMassB = lb.w;
 
-	for (u32 k = 0; k < count; ++k)
-	{
-		const float4* P = rowPlanes + (size_t)(k * MI_ROW_PLANES) * rowCap + s;
-		float4 p0 = P[0], p1 = P[rowCap], p2 = P[2 * rowCap], p3 = P[3 * rowCap], p4 = P[4 * rowCap], p5 = P[5 * rowCap];
-		float2 lam = rowLambda[(size_t)k * rowCap + s];
-		V3 rA = v3(p0.x, p0.y, p0.z), rB = v3(p0.w, p1.x, p1.y), t = v3(p1.z, p1.w, p2.x);
-		V3 JnA = v3(p2.y, p2.z, p2.w), JtA = v3(p3.x, p3.y, p3.z), JnB = v3(p3.w, p4.x, p4.y), JtB = v3(p4.z, p4.w, p5.x);
-		float mN = p5.y, mT = p5.z, bias = p5.w;
-		float impulseN = lam.x, impulseT = lam.y;
-		{ // tangent (constraints.cpp:3404-3424)
-			V3 rel = (vB + cross(wB, rB)) - (vA + cross(wA, rA));
-			float vt = dot(rel, t);
-			float lambda = -mT * vt;
-			float maxFriction = friction * impulseN;
-			float newImpulse = clampf(impulseT + lambda, -maxFriction, maxFriction);
-			lambda = newImpulse - impulseT;
-			impulseT = newImpulse;
-			V3 Pv = lambda * t;
-			vA -= invMassA * Pv; wA -= JtA * lambda;
-			vB += invMassB * Pv; wB += JtB * lambda;
-		}
-		{ // normal (constraints.cpp:3426-3442)
-			V3 rel = (vB + cross(wB, rB)) - (vA + cross(wA, rA));
-			float vn = dot(rel, n);
-			float lambda = -mN * (vn - bias);
-			float impulse = fmaxf(impulseN + lambda, 0.f);
-			lambda = impulse - impulseN;
-			impulseN = impulse;
-			V3 Pv = lambda * n;
-			vA -= invMassA * Pv; wA -= JnA * lambda;
-			vB += invMassB * Pv; wB += JnB * lambda;
-		}
-		rowLambda[(size_t)k * rowCap + s] = make_float2(impulseN, impulseT);
-	}
+	solveRow(r0, n, friction, invMassA, invMassB, vA, wA, vB, wB);
+	rowLambda[s] = r0.lam;
+	if (count > 1) { solveRow(r1, n, friction, invMassA, invMassB, vA, wA, vB, wB); rowLambda[rowCap + s] = r1.lam; }
+	if (count > 2) { solveRow(r2, n, friction, invMassA, invMassB, vA, wA, vB, wB); rowLambda[2 * rowCap + s] = r2.lam; }
+	if (count > 3) { solveRow(r3, n, friction, invMassA, invMassB, vA, wA, vB, wB); rowLambda[3 * rowCap + s] = r3.lam; }
+
 	if (a < nb) { vel[2 * a] = make_float4(vA.x, vA.y, vA.z, invMassA); vel[2 * a + 1] = make_float4(wA.x, wA.y, wA.z, 0.f); }
 	if (b < nb) { vel[2 * b] = make_float4(vB.x, vB.y, vB.z, invMassB); vel[2 * b + 1] = make_float4(wB.x, wB.y, wB.z, 0.f); }
 }
 
-__global__ void __launch_bounds__(256) k_solve_color(u32 start, u32 end, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes, const float4* __restrict__ rowShared,
-	float2* __restrict__ rowLambda, const uint4* __restrict__ rowIds, float4* __restrict__ vel)
+// One colour of the schedule.  The slot range and the contact-count boundaries are read from the device counters (written by
+// k_color_offsets), so the launch carries no per-step arguments and the whole 30-iteration sweep replays as one hipGraph.
+// Slots below b3/b2/b1 hold manifolds with 4/>=3/>=2 contacts.  Grid-stride: a stale (smaller) grid stays correct.
+__global__ void __launch_bounds__(256) k_solve_color(u32 color, const u32* __restrict__ counters, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes,
+	const float4* __restrict__ rowShared, float2* __restrict__ rowLambda, const uint4* __restrict__ rowIds, float4* __restrict__ vel)
 {
-	u32 s = start + blockIdx.x * blockDim.x + threadIdx.x;
-	if (s >= end) return;
-	solveManifold(s, nb, rowCap, rowPlanes, rowShared, rowLambda, rowIds, vel);
+	const u32* k = counters + CTR_KEY_START + 4 * color;
+	u32 start = k[0], b3 = k[1], b2 = k[2], b1 = k[3], end = k[4];
+	for (u32 s = start + blockIdx.x * blockDim.x + threadIdx.x; s < end; s += gridDim.x * blockDim.x)
+	{
+		u32 count = 1u + (s < b1) + (s < b2) + (s < b3);
+		solveManifold(s, count, nb, rowCap, rowPlanes, rowShared, rowLambda, rowIds, vel);
+	}
 }
 
 // Overflow bucket: bodies with more than 64 simultaneously touching partners.  Sequential, one lane, in slot order.
-__global__ void k_solve_serial(u32 start, u32 end, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes, const float4* __restrict__ rowShared,
+__global__ void k_solve_serial(const u32* __restrict__ counters, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes, const float4* __restrict__ rowShared,
 	float2* __restrict__ rowLambda, const uint4* __restrict__ rowIds, float4* __restrict__ vel)
 {
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	for (u32 s = start; s < end; ++s) solveManifold(s, nb, rowCap, rowPlanes, rowShared, rowLambda, rowIds, vel);
+	u32 start = counters[CTR_KEY_START + 4 * MI_SERIAL_COLOR], end = counters[CTR_KEY_START + 4 * MI_SERIAL_COLOR + 4];
+	for (u32 s = start; s < end; ++s) solveManifold(s, rowIds[s].z, nb, rowCap, rowPlanes, rowShared, rowLambda, rowIds, vel);
 }
 
-// One Gauss-Seidel iteration over all contact colours.  `colorStart` is the host copy read back after colouring.
-void launch_solve_contacts_iteration(World& w, const u32* colorStart, u32 numColors)
+// One Gauss-Seidel iteration over all contact colours; colour c is launched with gridBlocks[c] blocks (0 = skip).
+void launch_solve_contacts_iteration(World& w, const u32* gridBlocks, u32 numColors, bool serialBucket)
 {
 	for (u32 c = 0; c < numColors; ++c)
 	{
-		u32 start = colorStart[c], end = colorStart[c + 1];
-		if (end <= start) continue;
-		hipLaunchKernelGGL(k_solve_color, dim3((end - start + 255) / 256), dim3(256), 0, w.stream, start, end, w.nb, w.rowCap, w.rowPlanes.p, w.rowShared.p,
+		if (!gridBlocks[c]) continue;
+		hipLaunchKernelGGL(k_solve_color, dim3(gridBlocks[c]), dim3(256), 0, w.stream, c, w.dCounters.p, w.nb, w.rowCap, w.rowPlanes.p, w.rowShared.p,
 			w.rowLambda.p, w.rowIds.p, w.vel.p);
 	}
-	u32 sStart = colorStart[MI_SERIAL_COLOR], sEnd = colorStart[MI_SERIAL_COLOR + 1];
-	if (sEnd > sStart)
-		hipLaunchKernelGGL(k_solve_serial, dim3(1), dim3(64), 0, w.stream, sStart, sEnd, w.nb, w.rowCap, w.rowPlanes.p, w.rowShared.p, w.rowLambda.p, w.rowIds.p, w.vel.p);
+	if (serialBucket)
+		hipLaunchKernelGGL(k_solve_serial, dim3(1), dim3(64), 0, w.stream, w.dCounters.p, w.nb, w.rowCap, w.rowPlanes.p, w.rowShared.p, w.rowLambda.p, w.rowIds.p, w.vel.p);
 }

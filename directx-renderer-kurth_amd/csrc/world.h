@@ -55,13 +55,24 @@ struct JointSet
 	u32 count() const { return (u32)a.size(); }
 };
 
-struct StepCounters // device -> host each step (pinned)
+// Device-side step counters (u32 words of World::dCounters), copied to pinned host memory twice per step.
+enum
 {
-	u32 numPairs, numValidPairs, numManifolds, numContacts, numColors, numLarge, coloringRoundsLeft, overflow;
-	u32 colorStart[MI_MAX_COLORS + 2];
-	u32 bucketStart[32];
-	float cellSize; u32 pad[3];
+	CTR_NUM_PAIRS = 0,      // broadphase overlaps
+	CTR_NUM_VALID = 1,      // candidate pairs that survive prune/classify (= manifold slots)
+	CTR_NUM_MANIFOLDS = 2,  // slots with >= 1 contact
+	CTR_EPA_COUNT = 3,      // GJK hits waiting for EPA
+	CTR_NUM_COLORS = 4,
+	CTR_FIRST_LARGE = 5,    // sorted position of the first "large" collider
+	CTR_LAST_ROUND = 6,     // last colouring round that coloured anything
+	CTR_OVERFLOW = 7,       // manifolds sent to the serial bucket because the round budget ran out
+	CTR_CELL_SIZE = 8,      // float bits: largest extent of a collider riding on a rigid body
+	CTR_NUM_ACTIVE = 9,     // append cursor of the active-manifold list
+	CTR_BUCKET_START = 16,  // 65 words: first slot of narrowphase bucket key b (tA*6+tB); [64] unused
+	CTR_KEY_START = 96,     // (MI_MAX_COLORS+1)*4 + 1 words: first schedule slot of key colour*4 + (4-count); last = numManifolds
+	CTR_WORDS = 512,
 };
+#define MI_NUM_SCHEDULE_KEYS ((MI_MAX_COLORS + 1) * 4)
 
 struct World
 {
@@ -94,17 +105,32 @@ struct World
 	DevBuf<ManifoldRec> manifolds;
 	// colouring / solver
 	DevBuf<u64> bodyMask, claim; DevBuf<u32> mColor, mKey, mKeySorted, mIdx, mOrder;
+	DevBuf<uint4> actIds;                 // active manifolds: (bodyA, bodyB, count, slot)
+	DevBuf<u32> epaList; DevBuf<float4> gjkSimplex; // GJK hits -> EPA work list (9 float4 per hit)
 	DevBuf<float4> rowPlanes, rowShared; DevBuf<float2> rowLambda; DevBuf<uint4> rowIds;
 	DevBuf<uint8_t> tempStorage;
-	DevBuf<u32> dCounters; StepCounters* hCounters = nullptr;
+	DevBuf<u32> dCounters; u32* hCounters = nullptr; // CTR_WORDS words each
 	size_t pairCap = 0, rowCap = 0;
 
 	// settings snapshot for the running step
 	u32 iterations = 30;
 	u32 coloringRounds = 24;     // adaptive: last useful round of the previous step + margin
+	u32 lastNumManifolds = 0;    // sizes the colouring-round launches of the next step
 	mi_stats stats = {};
 	std::vector<hipEvent_t> stageEvents;
 	bool timeStages = false;
+
+	// The N-iteration solver sweep (joint colours + contact colours per iteration) replayed as one hipGraph.  Launch arguments are
+	// step-invariant (ranges live in dCounters), so a graph is rebuilt only when the colour count, a colour's size class, the joint
+	// schedule or a buffer address changes.
+	struct SolveGraph
+	{
+		hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr;
+		u32 numColors = 0, iterations = 0; bool serial = false; u32 jointVersion = 0; u64 bufferVersion = 0;
+		u32 gridBlocks[MI_MAX_COLORS] = {};
+	} solveGraph;
+	u32 jointVersion = 0; u64 bufferVersion = 0;
+	bool useGraph = true;
 
 	World(int dev);
 	~World();
@@ -124,7 +150,7 @@ void launch_narrowphase(World& w, u32 numPairs);
 void launch_integrate_forces(World& w, float dt);
 void launch_coloring(World& w, u32 numPairs);
 void launch_contact_init(World& w, u32 numPairs, float dt);
-void launch_solve_contacts_iteration(World& w, const u32* colorStart, u32 numColors);
+void launch_solve_contacts_iteration(World& w, const u32* gridBlocks, u32 numColors, bool serialBucket);
 void launch_integrate_velocities(World& w, float dt);
 void launch_joint_init(World& w, float dt);
 void launch_joint_solve_iteration(World& w);

@@ -40,10 +40,10 @@ World::World(int dev) : device(dev)
 	g_currentWorld = this;
 	MI_CHECK(hipSetDevice(dev));
 	MI_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-	MI_CHECK(hipHostMalloc((void**)&hCounters, sizeof(StepCounters) + 64, hipHostMallocDefault));
-	if (hCounters) memset(hCounters, 0, sizeof(StepCounters) + 64);
-	dCounters.ensure(256, stream);
-	if (dCounters.p) MI_CHECK(hipMemsetAsync(dCounters.p, 0, 256 * sizeof(u32), stream));
+	MI_CHECK(hipHostMalloc((void**)&hCounters, CTR_WORDS * sizeof(u32), hipHostMallocDefault));
+	if (hCounters) memset(hCounters, 0, CTR_WORDS * sizeof(u32));
+	dCounters.ensure(CTR_WORDS, stream);
+	if (dCounters.p) MI_CHECK(hipMemsetAsync(dCounters.p, 0, CTR_WORDS * sizeof(u32), stream));
 	stageEvents.resize(8);
 	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
 }
@@ -58,7 +58,7 @@ World::~World()
 		&mColor, &mKey, &mKeySorted, &mIdx, &mOrder, &dCounters };
 	for (auto b : u4) b->release();
 	colLocal.release(); colWorld.release(); sCellKey.release(); pairs.release(); pairsSorted.release(); manifolds.release(); bodyMask.release(); claim.release();
-	rowLambda.release(); rowIds.release(); tempStorage.release();
+	rowLambda.release(); rowIds.release(); tempStorage.release(); actIds.release(); epaList.release(); gjkSimplex.release();
 	for (auto& js : joints) { js.dPods.release(); js.dPairs.release(); js.dUpdate.release(); }
 	for (auto& e : stageEvents) if (e) (void)hipEventDestroy(e);
 	if (hCounters) (void)hipHostFree(hCounters);
@@ -274,7 +274,7 @@ void World::upload()
 		MI_CHECK(hipMemcpyAsync(colStaticPose.p, hsp.data(), sizeof(float4) * hsp.size(), hipMemcpyHostToDevice, stream));
 	}
 	MI_CHECK(hipStreamSynchronize(stream));
-	topologyDirty = false; stateOnDevice = true;
+	topologyDirty = false; stateOnDevice = true; bufferVersion++;
 	jointsDirty = true; // the static dummy index (= nb) moved
 }
 
@@ -322,7 +322,7 @@ void World::uploadJoints()
 		MI_CHECK(hipMemcpyAsync(js.dPairs.p, hpr.data(), sizeof(uint2) * m, hipMemcpyHostToDevice, stream));
 		MI_CHECK(hipStreamSynchronize(stream));
 	}
-	jointsDirty = false;
+	jointsDirty = false; jointVersion++;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -333,16 +333,63 @@ static void ensurePairBuffers(World& w, size_t numPairs)
 	if (numPairs <= w.pairCap) return;
 	size_t cap = std::max<size_t>(numPairs + numPairs / 2, 4096);
 	w.pairs.ensure(cap, w.stream, true); w.pairsSorted.ensure(2 * cap, w.stream); w.pairKey.ensure(cap, w.stream); w.pairKeySorted.ensure(cap, w.stream);
-	w.manifolds.ensure(cap, w.stream); w.mColor.ensure(cap, w.stream); w.mKey.ensure(cap, w.stream); w.mKeySorted.ensure(cap, w.stream); w.mIdx.ensure(cap, w.stream); w.mOrder.ensure(cap, w.stream);
+	w.manifolds.ensure(cap, w.stream); w.actIds.ensure(cap, w.stream); w.epaList.ensure(cap, w.stream); w.gjkSimplex.ensure(9 * cap, w.stream); w.mColor.ensure(cap, w.stream); w.mKey.ensure(cap, w.stream); w.mKeySorted.ensure(cap, w.stream); w.mIdx.ensure(cap, w.stream); w.mOrder.ensure(cap, w.stream);
 	w.rowPlanes.ensure((size_t)MI_MAX_CONTACTS_PER_MANIFOLD * MI_ROW_PLANES * cap, w.stream); w.rowShared.ensure(cap, w.stream);
 	w.rowLambda.ensure((size_t)MI_MAX_CONTACTS_PER_MANIFOLD * cap, w.stream); w.rowIds.ensure(cap, w.stream);
-	w.pairCap = cap; w.rowCap = cap;
+	w.pairCap = cap; w.rowCap = cap; w.bufferVersion++;
 }
 
 static void readCounters(World& w)
 {
-	MI_CHECK(hipMemcpyAsync(w.hCounters, w.dCounters.p, sizeof(StepCounters), hipMemcpyDeviceToHost, w.stream));
+	MI_CHECK(hipMemcpyAsync(w.hCounters, w.dCounters.p, CTR_WORDS * sizeof(u32), hipMemcpyDeviceToHost, w.stream));
 	MI_CHECK(hipStreamSynchronize(w.stream));
+}
+
+// solveOneIteration x N (constraints.cpp:3748-3772): per iteration all joint colours by type, then all contact colours.
+static void enqueueSolverSweep(World& w, u32 iters, const u32* gridBlocks, u32 numColors, bool serial)
+{
+	for (u32 it = 0; it < iters; ++it)
+	{
+		launch_joint_solve_iteration(w);
+		if (numColors || serial) launch_solve_contacts_iteration(w, gridBlocks, numColors, serial);
+	}
+}
+
+static void runSolverSweep(World& w, u32 iters, u32 numColors)
+{
+	const u32* keyStart = w.hCounters + CTR_KEY_START;
+	bool serial = numColors || w.hCounters[CTR_NUM_PAIRS] ? keyStart[4 * MI_SERIAL_COLOR + 4] > keyStart[4 * MI_SERIAL_COLOR] : false;
+	u32 need[MI_MAX_COLORS] = {};
+	for (u32 c = 0; c < numColors; ++c) need[c] = (keyStart[4 * c + 4] - keyStart[4 * c] + 255) / 256;
+	u32 numJointKernels = 0;
+	for (auto& js : w.joints) numJointKernels += js.colorStart.empty() ? 0 : (u32)js.colorStart.size() - 1;
+	if (!numColors && !serial && !numJointKernels) return;
+
+	World::SolveGraph& g = w.solveGraph;
+	if (!w.useGraph)
+	{
+		enqueueSolverSweep(w, iters, need, numColors, serial);
+		return;
+	}
+	bool reuse = g.exec && g.numColors == numColors && g.iterations == iters && g.serial == serial && g.jointVersion == w.jointVersion && g.bufferVersion == w.bufferVersion;
+	for (u32 c = 0; reuse && c < numColors; ++c)
+	{
+		// kernels grid-stride, so a cached grid stays correct; rebuild only when it is badly sized (> 2 passes or > 4x too wide)
+		if (need[c] > 2 * g.gridBlocks[c] || (g.gridBlocks[c] > 4 * std::max(need[c], 1u) && g.gridBlocks[c] > 8)) reuse = false;
+	}
+	if (!reuse)
+	{
+		if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+		if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+		for (u32 c = 0; c < MI_MAX_COLORS; ++c) g.gridBlocks[c] = (c < numColors) ? std::max(1u, need[c] + need[c] / 4) : 0;
+		MI_CHECK(hipStreamBeginCapture(w.stream, hipStreamCaptureModeThreadLocal));
+		enqueueSolverSweep(w, iters, g.gridBlocks, numColors, serial);
+		MI_CHECK(hipStreamEndCapture(w.stream, &g.graph));
+		if (g.graph) MI_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+		g.numColors = numColors; g.iterations = iters; g.serial = serial; g.jointVersion = w.jointVersion; g.bufferVersion = w.bufferVersion;
+		w.stats.numGraphBuilds++;
+	}
+	if (g.exec) MI_CHECK(hipGraphLaunch(g.exec, w.stream));
 }
 
 int World::stepInternal(float dt, u32 iters)
@@ -359,7 +406,7 @@ int World::stepInternal(float dt, u32 iters)
 	launch_build_colliders(*this);
 	launch_broadphase_count(*this);
 	readCounters(*this);                                   // sync #1: number of overlapping pairs
-	u32 numPairs = hCounters->numPairs;
+	u32 numPairs = hCounters[CTR_NUM_PAIRS];
 	ensurePairBuffers(*this, numPairs);
 	launch_broadphase_write(*this, numPairs);
 	if (T) MI_CHECK(hipEventRecord(stageEvents[1], stream));
@@ -375,28 +422,25 @@ int World::stepInternal(float dt, u32 iters)
 	if (numPairs)
 	{
 		readCounters(*this);                               // sync #2: colour boundaries of the contact schedule
-		numColors = hCounters->numColors;
+		numColors = hCounters[CTR_NUM_COLORS];
+		lastNumManifolds = hCounters[CTR_NUM_MANIFOLDS];
 		// adaptive colouring budget: last round that made progress + margin; grow quickly on overflow
-		u32 lastUseful = hCounters->coloringRoundsLeft;
-		coloringRounds = hCounters->overflow ? std::min(1024u, coloringRounds * 2) : std::max(12u, lastUseful + 6);
+		u32 lastUseful = hCounters[CTR_LAST_ROUND];
+		coloringRounds = hCounters[CTR_OVERFLOW] ? std::min(1024u, coloringRounds * 2) : std::max(12u, lastUseful + 6);
 	}
-	else { memset(hCounters->colorStart, 0, sizeof(hCounters->colorStart)); hCounters->numManifolds = 0; hCounters->numValidPairs = 0; }
+	else { memset(hCounters + CTR_KEY_START, 0, sizeof(u32) * (MI_NUM_SCHEDULE_KEYS + 1)); hCounters[CTR_NUM_MANIFOLDS] = 0; hCounters[CTR_NUM_VALID] = 0; lastNumManifolds = 0; }
 	if (T) MI_CHECK(hipEventRecord(stageEvents[3], stream));
 
-	for (u32 it = 0; it < iters; ++it)                     // solveOneIteration (constraints.cpp:3748-3772)
-	{
-		launch_joint_solve_iteration(*this);
-		if (numPairs) launch_solve_contacts_iteration(*this, hCounters->colorStart, numColors);
-	}
+	runSolverSweep(*this, iters, numPairs ? numColors : 0);
 	if (T) MI_CHECK(hipEventRecord(stageEvents[4], stream));
 
 	launch_integrate_velocities(*this, dt);
 	if (T) MI_CHECK(hipEventRecord(stageEvents[5], stream));
 
 	stats.numRigidBodies = nb; stats.numColliders = nc; stats.numBroadphaseOverlaps = numPairs;
-	stats.numCollisions = hCounters->numManifolds; stats.numColors = numColors; stats.numInternalSteps++;
+	stats.numCollisions = hCounters[CTR_NUM_MANIFOLDS]; stats.numColors = numColors; stats.numInternalSteps++;
 	u32 nj = 0; for (auto& js : joints) nj += (u32)js.order.size();
-	stats.numJoints = nj;
+	stats.numJoints = nj; stats.coloringRounds = coloringRounds;
 	if (T)
 	{
 		MI_CHECK(hipStreamSynchronize(stream));
@@ -769,8 +813,8 @@ static void d2h(World* w, void* dst, const void* src, size_t bytes)
 	if (!bytes) return;
 	MI_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, w->stream)); MI_CHECK(hipStreamSynchronize(w->stream));
 }
-uint32_t mi_debug_num_pairs(mi_world* world) { CHECK_WORLD(0); return W->hCounters->numPairs; }
-int mi_debug_read_pairs(mi_world* world, uint32_t* out) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); d2h(W, out, W->pairs.p, sizeof(uint2) * W->hCounters->numPairs); return W->lastError; }
+uint32_t mi_debug_num_pairs(mi_world* world) { CHECK_WORLD(0); return W->hCounters[CTR_NUM_PAIRS]; }
+int mi_debug_read_pairs(mi_world* world, uint32_t* out) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); d2h(W, out, W->pairs.p, sizeof(uint2) * W->hCounters[CTR_NUM_PAIRS]); return W->lastError; }
 int mi_debug_read_world_colliders(mi_world* world, void* outColliders64, float* outAabbs6)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
@@ -789,7 +833,7 @@ int mi_debug_read_world_colliders(mi_world* world, void* outColliders64, float* 
 	}
 	return W->lastError;
 }
-uint32_t mi_debug_num_manifold_slots(mi_world* world) { CHECK_WORLD(0); return W->hCounters->numPairs ? W->hCounters->numValidPairs : 0; }
+uint32_t mi_debug_num_manifold_slots(mi_world* world) { CHECK_WORLD(0); return W->hCounters[CTR_NUM_PAIRS] ? W->hCounters[CTR_NUM_VALID] : 0; }
 int mi_debug_read_manifolds(mi_world* world, uint32_t* outPairs2, uint32_t* outCounts, void* outContacts4x32, uint32_t* outBodyPairs2)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
@@ -816,9 +860,11 @@ uint32_t mi_debug_num_colors(mi_world* world) { CHECK_WORLD(0); return MI_MAX_CO
 int mi_debug_read_schedule(mi_world* world, uint32_t* outManifoldSlots, uint32_t* outColorStart)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
-	u32 n = W->hCounters->numPairs ? W->hCounters->numManifolds : 0;
-	d2h(W, outManifoldSlots, W->mOrder.p, sizeof(u32) * n);
-	memcpy(outColorStart, W->hCounters->colorStart, sizeof(u32) * (MI_MAX_COLORS + 2));
+	u32 n = W->hCounters[CTR_NUM_PAIRS] ? W->hCounters[CTR_NUM_MANIFOLDS] : 0;
+	std::vector<uint4> ids(n);
+	d2h(W, ids.data(), W->rowIds.p, sizeof(uint4) * n); // rowIds[s].w = manifold slot executed at schedule position s
+	for (u32 s = 0; s < n; ++s) outManifoldSlots[s] = ids[s].w;
+	for (u32 c = 0; c <= MI_MAX_COLORS + 1; ++c) outColorStart[c] = W->hCounters[CTR_KEY_START + 4 * c];
 	return W->lastError;
 }
 int mi_debug_read_joint_order(mi_world* world, uint32_t type, uint32_t* out)

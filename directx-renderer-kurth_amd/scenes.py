@@ -121,15 +121,15 @@ def c2_spheres(nx=22, ny=21, nz=22, seed=519431, radius=0.5, jitter=1e-3):
     return s
 
 
-def c3_mixed(n=100000, seed=14878213, area=200.0, column_height=50):
+def c3_mixed(n=100000, seed=14878213, area=200.0, column_height=50, pitch=1.4, layer=1.3):
     """C3/C5: n bodies, 1:1:1 sphere r in [0.3,0.6] / capsule (half-height 0.5, r 0.25) / OBB he in [0.3,0.8],
-    random orientations, poured as `column_height`-high columns on an area x area m ground."""
+    random orientations, poured as `column_height`-high columns (column pitch `pitch`, vertical spacing `layer`: a dense block
+    that is in contact from the first step and collapses outwards) on an area x area m ground."""
     rng = XorShift64(seed)
     s = Scene("c3_mixed_%d" % n)
     _ground(s, area * 0.5 + 10.0)
     ncol = (n + column_height - 1) // column_height
     side = int(math.ceil(math.sqrt(ncol)))
-    pitch = area / side
     i = 0
     for c in range(ncol):
         cx = (c % side - 0.5 * (side - 1)) * pitch
@@ -137,7 +137,7 @@ def c3_mixed(n=100000, seed=14878213, area=200.0, column_height=50):
         for k in range(column_height):
             if i >= n:
                 break
-            pos = (cx + rng.between(-0.3, 0.3), 1.0 + 1.7 * k + rng.between(0, 0.1), cz + rng.between(-0.3, 0.3))
+            pos = (cx + rng.between(-0.1, 0.1), 1.0 + layer * k + rng.between(0, 0.05), cz + rng.between(-0.1, 0.1))
             rot = rng.unit_quat()
             b = s.add_body(pos, rot)
             kind = i % 3
@@ -280,4 +280,6 @@ def by_name(name):
         return c4_ragdolls(4)
     if name == "c5":
         return c3_mixed(1000000, area=700.0)
+    if name == "c3_mid":
+        return c3_mixed(20000)
     raise KeyError(name)

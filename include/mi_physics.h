@@ -61,6 +61,7 @@ typedef struct mi_stats
 {
 	uint32_t numRigidBodies, numColliders, numBroadphaseOverlaps, numCollisions, numContacts;
 	uint32_t numColors, numJoints, numInternalSteps;
+	uint32_t numGraphBuilds, coloringRounds; /* solver-sweep hipGraph (re)builds so far; colouring round budget of the last step */
 	float msCollidersBroad, msNarrow, msSolverSetup, msSolve, msIntegrate, msTotal; /* HIP-event times, only when timing is enabled */
 } mi_stats;
 

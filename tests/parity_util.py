@@ -34,8 +34,22 @@ def follow_step(gpu, orc_world, scene_dt, iterations=30, joint_counts=None):
     orc_world.step_internal(scene_dt, iterations)
     o_pairs = orc_world.pairs()
     o_counts = orc_world.slot_counts().astype(np.uint32)
+    gs, os_ = pair_set(g_pairs), pair_set(o_pairs)
+    pairs_ok = np.array_equal(gs, os_)
+    num_ties = 0
+    if not pairs_ok:
+        # The reference's sort-and-sweep drops a pair whose endpoints TIE on the sorting axis depending on the previous frame's
+        # endpoint order (stable insertion sort with '>', collision_broad.cpp:387-398) although aabbVsAABB is inclusive
+        # (bounding_volumes.h:352-358).  The device reports the inclusive set; accept exactly those extra pairs.
+        extra = np.setdiff1d(gs, os_); missing = np.setdiff1d(os_, gs)
+        _, aabbs = orc_world.world_colliders()
+        axis = orc_world.sorting_axis()[0]
+        i = (extra & np.uint64(0xFFFFFFFF)).astype(np.int64); j = (extra >> np.uint64(32)).astype(np.int64)
+        tie = (aabbs[i, 3 + axis] == aabbs[j, axis]) | (aabbs[j, 3 + axis] == aabbs[i, axis])
+        pairs_ok = len(missing) == 0 and bool(tie.all())
+        num_ties = int(len(extra))
     out = {
-        "pairs_equal": np.array_equal(pair_set(g_pairs), pair_set(o_pairs)),
+        "pairs_equal": pairs_ok, "num_tie_pairs": num_ties,
         "num_pairs": len(g_pairs), "num_slots": len(slots), "num_manifolds": int((g_counts > 0).sum()),
         "counts_equal": np.array_equal(g_counts, o_counts[:len(g_counts)]) and len(o_counts) == len(g_counts),
         "num_colors": int((np.diff(cs[:65].astype(np.int64)) > 0).sum()),
