@@ -1,0 +1,147 @@
+"""bench.py — physics steps/sec of the MI355X rigid-body stepper on BASELINE.json's headline config.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c1|c3_mid] [--no-cpu-baseline]
+
+N = 1: the workload is config 3 ("100k mixed colliders (sphere/capsule/OBB) + contacts, 1 MI355X"): 100 000 bodies poured as a
+dense block, settled for 240 steps (untimed), then W warm-up steps and K timed steps of one physicsStepInternal each (dt = 1/120 s,
+30 solver iterations), state resident in HBM, no host read-back inside the timed region.
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the same world cut into N spatial slabs with a ghost-body halo
+exchange per step (directx-renderer-kurth_amd/parallel.py); "scaling": "strong".
+
+One JSON line on rank 0.  `roofline` prices the dominant kernel (contact solve, k_solve_color) with the fixed algorithmic figure of
+BASELINE.md (240 B per contact per iteration) against HIP-event time measured on the world's stream inside the timed region;
+`cpu_baseline` times the oracle's 8-lane "AVX2 restatement" of the reference solver (single thread) on a bounded sample of the same
+settled scene.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGORITHMIC_BYTES_PER_CONTACT_ITERATION = 240.0  # BASELINE.md / SURVEY §8(d)
+HBM_PEAK_GBPS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
+WORKLOADS = {"c1": ("64 OBBs on a ground plane", 120), "c2": ("10k stacked spheres", 240), "c3": ("100k mixed colliders (sphere/capsule/OBB)", 240),
+             "c3_mid": ("20k mixed colliders", 240), "c4": ("256 ragdolls (hinge + cone-twist chains)", 120), "c5": ("1M mixed colliders", 240)}
+
+
+def cpu_baseline(scene, transforms, velocities, seconds=12.0, max_steps=40):
+    """Oracle 8-lane path (liboracle_avx2.so, -O3 -mavx2 -mfma), one thread, started from the device's settled state."""
+    from oracle import oracle as orc
+    w = scene.instantiate(orc.OracleWorld(avx2=True, solver=orc.SOLVER_WIDE8))
+    w.write_state(transforms, velocities, presort=True)
+    w.step_internal(scene.dt)  # untimed: first broadphase after the state injection
+    n = 0
+    t0 = time.perf_counter()
+    while n < max_steps and (n < 2 or time.perf_counter() - t0 < seconds):
+        w.step_internal(scene.dt)
+        n += 1
+    dt = time.perf_counter() - t0
+    contacts = len(w.contacts()[0])
+    return {"value": n / dt, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": "%d steps of the same settled scene (%d contacts), oracle 8-lane AVX2 restatement of the reference solver, 1 thread; "
+                      "the reference binary itself cannot be built (MSVC/Windows) and its u16 indices cannot hold this config" % (n, contacts)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--settle", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        args.gpus = world_size
+
+    import torch
+    import directx_renderer_kurth_amd as mi
+    from directx_renderer_kurth_amd import scenes
+
+    label, default_settle = WORKLOADS[args.workload]
+    settle = default_settle if args.settle < 0 else args.settle
+    scene = scenes.by_name(args.workload)
+    torch.cuda.set_device(local_rank)
+
+    if world_size > 1:
+        import torch.distributed as dist
+        from directx_renderer_kurth_amd import parallel
+        dist.init_process_group("nccl")
+        stepper = parallel.SlabWorld(scene, device=local_rank, rank=rank, world_size=world_size)
+        barrier = dist.barrier
+    else:
+        dist = None
+        stepper = scene.instantiate(mi.World(device=local_rank))
+        barrier = lambda: None
+
+    def sync():
+        stepper.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(settle):
+        stepper.step_internal(scene.dt)
+    for _ in range(args.warmup):
+        stepper.step_internal(scene.dt)
+    stepper.enable_stage_timing(True)  # HIP events on the world's stream, inside the timed region
+    acc = {}
+    barrier(); sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper.step_internal(scene.dt)
+        st = stepper.stats()
+        for k, v in st.items():
+            acc[k] = acc.get(k, 0.0) + v
+    barrier(); sync()
+    elapsed = time.perf_counter() - t0
+    stepper.enable_stage_timing(False)
+
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        stepper.gather_stats(acc)
+
+    if rank == 0:
+        K = args.steps
+        mean = {k: v / K for k, v in acc.items()}
+        ms_per_step = elapsed / K * 1e3
+        contacts = mean["numContacts"]
+        launches_per_step = max(1.0, mean["numColors"]) * 30.0
+        bytes_per_step = ALGORITHMIC_BYTES_PER_CONTACT_ITERATION * contacts * 30.0
+        solve_s = mean["msSolve"] * 1e-3
+        achieved = bytes_per_step / solve_s / 1e9 if solve_s > 0 else 0.0
+        out = {
+            "metric": "physics steps/sec at 100k rigid bodies" if args.workload == "c3" else "physics steps/sec", "value": K / elapsed, "unit": "steps/s",
+            "n_gpus": world_size, "steps": K, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s, dt 1/%d s, 30 solver iterations, settled %d steps" % (args.workload, label, round(1.0 / scene.dt), settle),
+                       "bodies": scene.num_bodies, "broadphase_pairs": round(mean["numBroadphaseOverlaps"]), "manifolds": round(mean["numCollisions"]),
+                       "contacts": round(contacts), "colors": round(mean["numColors"], 1), "joints": round(mean["numJoints"]),
+                       "parallelism": "1 gpu" if world_size == 1 else "%d spatial slabs + ghost-body halo over RCCL" % world_size},
+            "stage_ms": {k: round(mean[k], 4) for k in ("msCollidersBroad", "msNarrow", "msSolverSetup", "msSolve", "msIntegrate", "msTotal")},
+            "roofline": {"bound": "hbm", "kernel": "k_solve_color (contact PGS sweep)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_per_step / launches_per_step, "avg_launch_us": solve_s / launches_per_step * 1e6,
+                         "launches_per_step": launches_per_step},
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, stepper.transforms(1), stepper.velocities())
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

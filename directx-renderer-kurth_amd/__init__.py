@@ -61,7 +61,7 @@ EXPORTED_SYMBOLS = [
     "mi_add_distance_constraint_local", "mi_add_distance_constraint_global", "mi_add_ball_constraint_local", "mi_add_ball_constraint_global",
     "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
     "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_apply_force_torque", "mi_set_velocity",
-    "mi_set_transform", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
+    "mi_set_transform", "mi_write_transforms", "mi_write_velocities", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
     "mi_get_stats", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_debug_num_pairs", "mi_debug_read_pairs",
     "mi_debug_read_world_colliders", "mi_debug_num_manifold_slots", "mi_debug_read_manifolds", "mi_debug_num_colors", "mi_debug_read_schedule",
     "mi_debug_read_joint_order", "mi_debug_read_body_state",
@@ -192,6 +192,12 @@ class World:
 
     def set_velocity(self, body, lin, ang=(0, 0, 0)):
         self._check(self.lib.mi_set_velocity(self.w, body, _f(lin), _f(ang)))
+
+    def write_state(self, transforms, velocities):
+        """Bulk overwrite of physics_transform1 ([n,7]) and velocities ([n,6])."""
+        t = np.ascontiguousarray(transforms, np.float32); v = np.ascontiguousarray(velocities, np.float32)
+        self._check(self.lib.mi_write_transforms(self.w, _p(t), C.c_uint32(len(t))))
+        self._check(self.lib.mi_write_velocities(self.w, _p(v), C.c_uint32(len(v))))
 
     # ---- stepping -------------------------------------------------------------------------------------------
     def step(self, dt, settings=None):

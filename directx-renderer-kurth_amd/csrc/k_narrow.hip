@@ -44,7 +44,7 @@ __global__ void k_bucket_offsets(u32* __restrict__ counters, const u32* __restri
 	u32 lo = 0, hi = n;
 	while (lo < hi) { u32 mid = (lo + hi) >> 1; if (keySorted[mid] < b) lo = mid + 1; else hi = mid; }
 	counters[CTR_BUCKET_START + b] = lo; // valid keys are <= 4*6+4 = 28; KEY_INVALID sorts last
-	if (b == KEY_INVALID) { counters[CTR_NUM_VALID] = lo; counters[CTR_EPA_COUNT] = 0; counters[CTR_NUM_ACTIVE] = 0; }
+	if (b == KEY_INVALID) { counters[CTR_NUM_VALID] = lo; counters[CTR_EPA_COUNT] = 0; counters[CTR_NUM_ACTIVE] = 0; counters[CTR_NUM_CONTACTS] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -483,8 +483,8 @@ MI_DEV bool obbObb(const Obb& a, const Obb& b, Man& m)
 // with 2x headroom, and the reference's out-of-memory exits are kept.
 // ---------------------------------------------------------------------------------------------------------------
 #define EPA_MAX_POINTS 24
-#define EPA_MAX_TRIANGLES 96
-#define EPA_MAX_EDGES 128
+#define EPA_MAX_TRIANGLES 128
+#define EPA_MAX_EDGES 160
 #define EPA_MAX_BORDER 32
 #define GJK_MAX_ITERATIONS 64
 
@@ -1046,6 +1046,6 @@ void launch_narrowphase(World& w, u32 numPairs)
 	hipLaunchKernelGGL(k_gjk, grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_CLOSED>), grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_BOX>), dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p);
-	u32 epaBlocks = std::min<u32>((numPairs + EPA_WAVES_PER_BLOCK - 1) / EPA_WAVES_PER_BLOCK, 256u * 5u); // 5 blocks of 4 waves fit a CU's LDS
+	u32 epaBlocks = std::min<u32>((numPairs + EPA_WAVES_PER_BLOCK - 1) / EPA_WAVES_PER_BLOCK, 256u * 4u); // 4 blocks of 4 waves (38.5 KB of LDS each) fit a CU
 	hipLaunchKernelGGL(k_epa, dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p);
 }

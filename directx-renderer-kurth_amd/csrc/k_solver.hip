@@ -32,6 +32,7 @@ __global__ void __launch_bounds__(256) k_active_list(u32* __restrict__ counters,
 	uint4 ids = manifolds[m].ids;
 	if (!ids.z) return;
 	u32 j = atomicAdd(&counters[CTR_NUM_ACTIVE], 1u);
+	atomicAdd(&counters[CTR_NUM_CONTACTS], ids.z);
 	actIds[j] = make_uint4(ids.x, ids.y, ids.z, m);
 	mColor[j] = UNCOLORED;
 }

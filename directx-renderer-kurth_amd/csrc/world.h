@@ -68,6 +68,7 @@ enum
 	CTR_OVERFLOW = 7,       // manifolds sent to the serial bucket because the round budget ran out
 	CTR_CELL_SIZE = 8,      // float bits: largest extent of a collider riding on a rigid body
 	CTR_NUM_ACTIVE = 9,     // append cursor of the active-manifold list
+	CTR_NUM_CONTACTS = 10,  // sum of contact counts over the active manifolds
 	CTR_BUCKET_START = 16,  // 65 words: first slot of narrowphase bucket key b (tA*6+tB); [64] unused
 	CTR_KEY_START = 96,     // (MI_MAX_COLORS+1)*4 + 1 words: first schedule slot of key colour*4 + (4-count); last = numManifolds
 	CTR_WORDS = 512,

@@ -46,6 +46,7 @@ World::World(int dev) : device(dev)
 	if (dCounters.p) MI_CHECK(hipMemsetAsync(dCounters.p, 0, CTR_WORDS * sizeof(u32), stream));
 	stageEvents.resize(8);
 	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
+	useGraph = getenv("MI_PHYSICS_NO_GRAPH") == nullptr; // rocprofv3's kernel trace needs plain launches
 }
 
 World::~World()
@@ -438,7 +439,7 @@ int World::stepInternal(float dt, u32 iters)
 	if (T) MI_CHECK(hipEventRecord(stageEvents[5], stream));
 
 	stats.numRigidBodies = nb; stats.numColliders = nc; stats.numBroadphaseOverlaps = numPairs;
-	stats.numCollisions = hCounters[CTR_NUM_MANIFOLDS]; stats.numColors = numColors; stats.numInternalSteps++;
+	stats.numCollisions = hCounters[CTR_NUM_MANIFOLDS]; stats.numContacts = numPairs ? hCounters[CTR_NUM_CONTACTS] : 0; stats.numColors = numColors; stats.numInternalSteps++;
 	u32 nj = 0; for (auto& js : joints) nj += (u32)js.order.size();
 	stats.numJoints = nj; stats.coloringRounds = coloringRounds;
 	if (T)
@@ -737,6 +738,41 @@ int mi_set_transform(mi_world* world, uint32_t body, const float pos[3], const f
 	return W->lastError;
 }
 
+int mi_write_transforms(mi_world* world, const float* in7, uint32_t n)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->upload();
+	n = std::min<u32>(n, W->nb);
+	if (!n) return W->lastError;
+	std::vector<float4> h(2 * (size_t)n);
+	for (u32 i = 0; i < n; ++i)
+	{
+		const float* s = in7 + 7 * (size_t)i;
+		h[2 * i] = make_float4(s[0], s[1], s[2], 0.f); h[2 * i + 1] = make_float4(s[3], s[4], s[5], s[6]);
+	}
+	MI_CHECK(hipMemcpyAsync(W->pose.p, h.data(), sizeof(float4) * h.size(), hipMemcpyHostToDevice, W->stream));
+	MI_CHECK(hipMemcpyAsync(W->pose0.p, h.data(), sizeof(float4) * h.size(), hipMemcpyHostToDevice, W->stream));
+	MI_CHECK(hipMemcpyAsync(W->poseLerp.p, h.data(), sizeof(float4) * h.size(), hipMemcpyHostToDevice, W->stream));
+	MI_CHECK(hipStreamSynchronize(W->stream));
+	return W->lastError;
+}
+int mi_write_velocities(mi_world* world, const float* in6, uint32_t n)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->upload();
+	n = std::min<u32>(n, W->nb);
+	if (!n) return W->lastError;
+	std::vector<float4> h(2 * (size_t)n);
+	for (u32 i = 0; i < n; ++i)
+	{
+		const float* s = in6 + 6 * (size_t)i;
+		h[2 * i] = make_float4(s[0], s[1], s[2], W->bodies[i].invMass); h[2 * i + 1] = make_float4(s[3], s[4], s[5], 0.f);
+	}
+	MI_CHECK(hipMemcpyAsync(W->vel.p, h.data(), sizeof(float4) * h.size(), hipMemcpyHostToDevice, W->stream));
+	MI_CHECK(hipStreamSynchronize(W->stream));
+	return W->lastError;
+}
+
 int mi_step(mi_world* world, float* timer, const mi_physics_settings* settings, float dt)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
@@ -794,7 +830,7 @@ int mi_read_mass_properties(mi_world* world, float* out13, uint32_t n)
 	}
 	return MI_OK;
 }
-int mi_get_stats(mi_world* world, mi_stats* out) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); *out = W->stats; out->numContacts = 0; return MI_OK; }
+int mi_get_stats(mi_world* world, mi_stats* out) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); *out = W->stats; return MI_OK; }
 int mi_enable_stage_timing(mi_world* world, int enable) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); W->timeStages = enable != 0; return MI_OK; }
 uint32_t mi_num_bodies(mi_world* world) { CHECK_WORLD(0); return (u32)W->bodies.size(); }
 uint32_t mi_num_colliders(mi_world* world) { CHECK_WORLD(0); return (u32)W->colliders.size(); }

@@ -104,6 +104,10 @@ int mi_delete_all_constraints(mi_world* w);                           /* deleteA
 int mi_apply_force_torque(mi_world* w, uint32_t body, const float force[3], const float torque[3]);
 int mi_set_velocity(mi_world* w, uint32_t body, const float linear[3], const float angular[3]);
 int mi_set_transform(mi_world* w, uint32_t body, const float pos[3], const float rot[4]);
+/* Bulk forms of the two setters above for the first n bodies: n x {pos3, quat4} / n x {linear3, angular3} (scene deserialisation,
+ * serialization_binary.cpp:237-260, and state hand-over between worlds). */
+int mi_write_transforms(mi_world* w, const float* in7, uint32_t n);
+int mi_write_velocities(mi_world* w, const float* in6, uint32_t n);
 
 /* ---- per-frame -------------------------------------------------------------------------------------------------- */
 /* void physicsStep(game_scene&, memory_arena&, float& timer, const physics_settings&, float dt): physics.h:405, physics.cpp:1364-1413.

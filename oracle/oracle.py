@@ -136,6 +136,12 @@ class OracleWorld:
     def set_velocity(self, body, lin, ang=(0, 0, 0)):
         assert self.lib.orc_set_velocity(self.w, body, _f(lin), _f(ang)) == 0
 
+    def write_state(self, transforms, velocities, presort=True):
+        t = np.ascontiguousarray(transforms, np.float32); v = np.ascontiguousarray(velocities, np.float32)
+        self.lib.orc_write_state(self.w, _p(t), _p(v), C.c_uint32(len(t)))
+        if presort:
+            self.lib.orc_presort_endpoints(self.w)
+
     # ---- stepping ---------------------------------------------------------------------------------------
     def step(self, dt, settings=None):
         """physicsStep(scene, arena, timer, settings, dt) — reference physics.h:405."""

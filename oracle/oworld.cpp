@@ -767,6 +767,33 @@ int orc_apply_force_torque(world* w, u32 b, const float* f, const float* t)
 	w->bodies[b].forceAccumulator += v3(f); w->bodies[b].torqueAccumulator += v3(t);
 	return 0;
 }
+// Bulk state injection (n x {pos3, quat4}, n x {lin3, ang3}) — lets bench.py time the CPU path on the device's settled scene.
+void orc_write_state(world* w, const float* in7, const float* in6, u32 n)
+{
+	for (u32 i = 0; i < n && i < w->bodies.size(); ++i)
+	{
+		body& b = w->bodies[i];
+		const float* t = in7 + 7 * (size_t)i; const float* v = in6 + 6 * (size_t)i;
+		b.transform.position = vec3(t[0], t[1], t[2]); b.transform.rotation = quat(t[3], t[4], t[5], t[6]);
+		b.transform0 = b.transform1 = b.transform;
+		b.linearVelocity = vec3(v[0], v[1], v[2]); b.angularVelocity = vec3(v[3], v[4], v[5]);
+	}
+}
+// Sorts the SAP endpoints of the CURRENT configuration with std::stable_sort so that the next broadphase's insertion sort starts
+// from temporal coherence (the reference pays its O(N^2) first-frame insertion sort once at scene load; a baseline sample that
+// starts from an injected state would otherwise time that one-off cost).
+void orc_presort_endpoints(world* w)
+{
+	getWorldSpaceColliders(*w);
+	u32 axis = w->sortingAxis;
+	for (sap_endpoint& ep : w->endpoints)
+	{
+		const bounding_box& aabb = w->worldSpaceAABBs[ep.collider];
+		ep.value = ep.start ? aabb.minCorner[axis] : aabb.maxCorner[axis];
+	}
+	std::stable_sort(w->endpoints.begin(), w->endpoints.end(), [](const sap_endpoint& a, const sap_endpoint& b) { return a.value < b.value; });
+}
+
 int orc_set_velocity(world* w, u32 b, const float* lin, const float* ang)
 {
 	if (b >= w->bodies.size()) return 1;

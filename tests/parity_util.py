@@ -20,8 +20,10 @@ def quat_dist(a, b):
     return np.minimum(d1, d2)
 
 
-def follow_step(gpu, orc_world, scene_dt, iterations=30, joint_counts=None):
-    """Step both worlds once; returns a dict of comparison metrics.  `orc_world.solver` must be SOLVER_CUSTOM."""
+def follow_step(gpu, orc_world, scene_dt, iterations=30, joint_counts=None, resync=False):
+    """Step both worlds once; returns a dict of comparison metrics.  `orc_world.solver` must be SOLVER_CUSTOM.
+    resync=True copies the oracle's state into the device world after the comparison, so every step starts from identical
+    inputs (used where libm-vs-device trigonometry makes free-running trajectories drift chaotically: joints)."""
     gpu.step_internal(scene_dt, iterations)
     g_pairs = gpu.pairs()
     slots, g_counts, g_contacts, g_bp = gpu.manifolds()
@@ -69,4 +71,6 @@ def follow_step(gpu, orc_world, scene_dt, iterations=30, joint_counts=None):
     out["rot_err"] = float(quat_dist(gt[:, 3:], ot[:, 3:]).max())
     out["vel_err"] = float(np.abs(gv - ov).max())
     out["vel_scale"] = float(np.abs(ov).max())
+    if resync:
+        gpu.write_state(ot, ov)
     return out
