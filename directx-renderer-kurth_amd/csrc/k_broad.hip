@@ -88,12 +88,17 @@ __global__ void __launch_bounds__(256) k_gather_sorted(u32 nc, u32 hashMask, con
 	else if (hPrev != h) { counters[CTR_FIRST_LARGE] = t; }
 }
 
-// Count (WRITE=false) or emit (WRITE=true) the overlapping partners of the collider at sorted position t.
-// A pair is produced by the member with the larger sorted position, as (A = this collider, B = partner).
-template <bool WRITE>
+// Overlapping partners of the collider at sorted position t.  Every pair is produced exactly once, as (A = this collider,
+// B = partner): partners in the 13 "forward" neighbour cells, partners sorted before t in the own cell, and every large collider.
+// MODE_SLAB  : one traversal; the first PAIR_SLAB partners go to a per-collider slab, the full count to pairCount.
+// MODE_WRITE : second traversal writing directly at pairOffset[t] — only used in the rare step where some collider has more than
+//              PAIR_SLAB partners (the slab pass sets CTR_PAIR_OVERFLOW); same traversal order, so the pair list is identical.
+#define PAIR_SLAB 32
+enum { MODE_SLAB = 0, MODE_WRITE = 1 };
+template <int MODE>
 __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* __restrict__ sCellKey, const float4* __restrict__ sMin, const float4* __restrict__ sMax,
-	const u32* __restrict__ cellStart, const u32* __restrict__ cellEnd, const u32* __restrict__ counters,
-	u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, uint2* __restrict__ pairs, u32 pairCap)
+	const u32* __restrict__ cellStart, const u32* __restrict__ cellEnd, u32* __restrict__ counters,
+	u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, uint2* __restrict__ out, u32 pairCap)
 {
 	u32 t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= nc) return;
@@ -101,55 +106,57 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* 
 	float4 amin = sMin[t], amax = sMax[t];
 	u32 me = __float_as_uint(amin.w);
 	u32 n = 0;
-	u32 out = WRITE ? pairOffset[t] : 0;
+	size_t base = (MODE == MODE_WRITE) ? (size_t)pairOffset[t] : (size_t)t * PAIR_SLAB;
+	u32 room = (MODE == MODE_WRITE) ? 0xFFFFFFFFu : PAIR_SLAB;
+#define EMIT(PARTNER) { if (n < room && (MODE == MODE_SLAB || base + n < pairCap)) out[base + n] = make_uint2(me, (PARTNER)); ++n; }
 
 	if (t >= firstLarge)
 	{
 		for (u32 u = firstLarge; u < t; ++u)
 		{
 			float4 bmin = sMin[u], bmax = sMax[u];
-			if (aabbOverlap(amin, amax, bmin, bmax))
-			{
-				if (WRITE) { if (out + n < pairCap) pairs[out + n] = make_uint2(me, __float_as_uint(bmin.w)); }
-				++n;
-			}
+			if (aabbOverlap(amin, amax, bmin, bmax)) EMIT(__float_as_uint(bmin.w))
 		}
 	}
 	else
 	{
 		u64 key = sCellKey[t];
 		i32 ix = (i32)(key & CELL_MASK), iy = (i32)((key >> 21) & CELL_MASK), iz = (i32)((key >> 42) & CELL_MASK);
-		for (i32 dz = -1; dz <= 1; ++dz)
-		for (i32 dy = -1; dy <= 1; ++dy)
-		for (i32 dx = -1; dx <= 1; ++dx)
+		for (i32 o = 13; o < 27; ++o) // offsets (dz,dy,dx) >= (0,0,0) in lexicographic order: own cell first, then the forward half
 		{
+			i32 dz = o / 9 - 1, dy = (o / 3) % 3 - 1, dx = o % 3 - 1;
 			u64 nkey = packCell(ix + dx, iy + dy, iz + dz);
 			u32 h = hashCell(nkey, hashMask);
 			u32 s = cellStart[h];
 			if (s == EMPTY_CELL) continue;
-			u32 e = min(cellEnd[h], t); // only partners sorted before me
+			u32 e = cellEnd[h];
+			if (o == 13) e = min(e, t); // own cell: only partners sorted before me
 			for (u32 u = s; u < e; ++u)
 			{
 				if (sCellKey[u] != nkey) continue; // other cell sharing the hash bucket
 				float4 bmin = sMin[u], bmax = sMax[u];
-				if (aabbOverlap(amin, amax, bmin, bmax))
-				{
-					if (WRITE) { if (out + n < pairCap) pairs[out + n] = make_uint2(me, __float_as_uint(bmin.w)); }
-					++n;
-				}
+				if (aabbOverlap(amin, amax, bmin, bmax)) EMIT(__float_as_uint(bmin.w))
 			}
 		}
 		for (u32 u = firstLarge; u < nc; ++u)
 		{
 			float4 bmin = sMin[u], bmax = sMax[u];
-			if (aabbOverlap(amin, amax, bmin, bmax))
-			{
-				if (WRITE) { if (out + n < pairCap) pairs[out + n] = make_uint2(me, __float_as_uint(bmin.w)); }
-				++n;
-			}
+			if (aabbOverlap(amin, amax, bmin, bmax)) EMIT(__float_as_uint(bmin.w))
 		}
 	}
-	if (!WRITE) pairCount[t] = n;
+#undef EMIT
+	if (MODE == MODE_SLAB) { pairCount[t] = n; if (n > PAIR_SLAB) counters[CTR_PAIR_OVERFLOW] = 1; }
+}
+
+// Packs the per-collider slabs into the dense, deterministic pair list (order: sorted position, then traversal order).
+__global__ void __launch_bounds__(256) k_pairs_pack(u32 nc, const u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, const uint2* __restrict__ slab,
+	uint2* __restrict__ pairs, u32 pairCap)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x; // one lane per slab entry
+	u32 t = i / PAIR_SLAB, k = i % PAIR_SLAB;
+	if (t >= nc || k >= pairCount[t]) return;
+	u32 dst = pairOffset[t] + k;
+	if (dst < pairCap) pairs[dst] = slab[i];
 }
 
 __global__ void k_finish_pair_count(u32 nc, const u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, u32* __restrict__ counters)
@@ -206,8 +213,10 @@ void launch_broadphase_count(World& w)
 	MI_CHECK(hipMemcpyAsync(w.dCounters.p + CTR_FIRST_LARGE, &ncAsFirstLarge, sizeof(u32), hipMemcpyHostToDevice, w.stream));
 	hipLaunchKernelGGL(k_gather_sorted, grid, block, 0, w.stream, nc, mask, w.hashKeySorted.p, w.sortIdxSorted.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p,
 		w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<false>), grid, block, 0, w.stream, nc, mask, w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p, w.dCounters.p,
-		w.pairCount.p, w.pairOffset.p, w.pairs.p, 0u);
+	w.pairSlab.ensure((size_t)nc * PAIR_SLAB, w.stream);
+	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_PAIR_OVERFLOW, 0, sizeof(u32), w.stream));
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_SLAB>), grid, block, 0, w.stream, nc, mask, w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p, w.dCounters.p,
+		w.pairCount.p, w.pairOffset.p, w.pairSlab.p, 0u);
 	prim_exclusive_scan_u32(w, w.pairCount.p, w.pairOffset.p, nc);
 	hipLaunchKernelGGL(k_finish_pair_count, dim3(1), dim3(64), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.dCounters.p);
 }
@@ -216,6 +225,9 @@ void launch_broadphase_write(World& w, u32 numPairs)
 {
 	u32 nc = w.nc;
 	if (!nc || !numPairs) return;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<true>), dim3((nc + 255) / 256), dim3(256), 0, w.stream, nc, w.hashTableSize - 1, w.sCellKey.p, w.sMin.p, w.sMax.p,
-		w.cellStart.p, w.cellEnd.p, w.dCounters.p, w.pairCount.p, w.pairOffset.p, w.pairs.p, (u32)w.pairCap);
+	if (w.hCounters[CTR_PAIR_OVERFLOW]) // some collider has more than PAIR_SLAB partners: redo the traversal, writing in place
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_WRITE>), dim3((nc + 255) / 256), dim3(256), 0, w.stream, nc, w.hashTableSize - 1, w.sCellKey.p, w.sMin.p, w.sMax.p,
+			w.cellStart.p, w.cellEnd.p, w.dCounters.p, w.pairCount.p, w.pairOffset.p, w.pairs.p, (u32)w.pairCap);
+	else
+		hipLaunchKernelGGL(k_pairs_pack, dim3((u32)(((size_t)nc * PAIR_SLAB + 255) / 256)), dim3(256), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.pairSlab.p, w.pairs.p, (u32)w.pairCap);
 }

@@ -69,6 +69,7 @@ enum
 	CTR_CELL_SIZE = 8,      // float bits: largest extent of a collider riding on a rigid body
 	CTR_NUM_ACTIVE = 9,     // append cursor of the active-manifold list
 	CTR_NUM_CONTACTS = 10,  // sum of contact counts over the active manifolds
+	CTR_PAIR_OVERFLOW = 11, // some collider has more broadphase partners than its slab holds
 	CTR_BUCKET_START = 16,  // 65 words: first slot of narrowphase bucket key b (tA*6+tB); [64] unused
 	CTR_KEY_START = 96,     // (MI_MAX_COLORS+1)*4 + 1 words: first schedule slot of key colour*4 + (4-count); last = numManifolds
 	CTR_WORDS = 512,
@@ -99,7 +100,7 @@ struct World
 	// broadphase
 	DevBuf<u32> hashKey, hashKeySorted, sortIdx, sortIdxSorted, cellStart, cellEnd, largeFlag, largeScan, largeList, pairCount, pairOffset;
 	DevBuf<u64> sCellKey; DevBuf<float4> sMin, sMax;
-	DevBuf<uint2> pairs;
+	DevBuf<uint2> pairs, pairSlab;
 	u32 hashTableSize = 0;
 	// narrowphase
 	DevBuf<u32> pairKey, pairKeySorted; DevBuf<uint2> pairsSorted;
@@ -127,7 +128,7 @@ struct World
 	struct SolveGraph
 	{
 		hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr;
-		u32 numColors = 0, iterations = 0; bool serial = false; u32 jointVersion = 0; u64 bufferVersion = 0;
+		u32 numColors = 0, firstTail = 0, iterations = 0; bool serial = false; u32 jointVersion = 0; u64 bufferVersion = 0;
 		u32 gridBlocks[MI_MAX_COLORS] = {};
 	} solveGraph;
 	u32 jointVersion = 0; u64 bufferVersion = 0;
@@ -151,7 +152,7 @@ void launch_narrowphase(World& w, u32 numPairs);
 void launch_integrate_forces(World& w, float dt);
 void launch_coloring(World& w, u32 numPairs);
 void launch_contact_init(World& w, u32 numPairs, float dt);
-void launch_solve_contacts_iteration(World& w, const u32* gridBlocks, u32 numColors, bool serialBucket);
+void launch_solve_contacts_iteration(World& w, const u32* gridBlocks, u32 numColors, u32 firstTail, bool serialBucket);
 void launch_integrate_velocities(World& w, float dt);
 void launch_joint_init(World& w, float dt);
 void launch_joint_solve_iteration(World& w);

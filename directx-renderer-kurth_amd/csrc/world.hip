@@ -59,7 +59,7 @@ World::~World()
 		&mColor, &mKey, &mKeySorted, &mIdx, &mOrder, &dCounters };
 	for (auto b : u4) b->release();
 	colLocal.release(); colWorld.release(); sCellKey.release(); pairs.release(); pairsSorted.release(); manifolds.release(); bodyMask.release(); claim.release();
-	rowLambda.release(); rowIds.release(); tempStorage.release(); actIds.release(); epaList.release(); gjkSimplex.release();
+	rowLambda.release(); rowIds.release(); tempStorage.release(); actIds.release(); epaList.release(); gjkSimplex.release(); pairSlab.release();
 	for (auto& js : joints) { js.dPods.release(); js.dPairs.release(); js.dUpdate.release(); }
 	for (auto& e : stageEvents) if (e) (void)hipEventDestroy(e);
 	if (hCounters) (void)hipHostFree(hCounters);
@@ -347,21 +347,32 @@ static void readCounters(World& w)
 }
 
 // solveOneIteration x N (constraints.cpp:3748-3772): per iteration all joint colours by type, then all contact colours.
-static void enqueueSolverSweep(World& w, u32 iters, const u32* gridBlocks, u32 numColors, bool serial)
+static void enqueueSolverSweep(World& w, u32 iters, const u32* gridBlocks, u32 numColors, u32 firstTail, bool serial)
 {
 	for (u32 it = 0; it < iters; ++it)
 	{
 		launch_joint_solve_iteration(w);
-		if (numColors || serial) launch_solve_contacts_iteration(w, gridBlocks, numColors, serial);
+		if (numColors || serial) launch_solve_contacts_iteration(w, gridBlocks, numColors, firstTail, serial);
 	}
 }
+
+static const u32 TAIL_MAX_MANIFOLDS = 2048; // colours at the end of the schedule no larger than this go to the one-workgroup tail kernel
 
 static void runSolverSweep(World& w, u32 iters, u32 numColors)
 {
 	const u32* keyStart = w.hCounters + CTR_KEY_START;
 	bool serial = numColors || w.hCounters[CTR_NUM_PAIRS] ? keyStart[4 * MI_SERIAL_COLOR + 4] > keyStart[4 * MI_SERIAL_COLOR] : false;
-	u32 need[MI_MAX_COLORS] = {};
-	for (u32 c = 0; c < numColors; ++c) need[c] = (keyStart[4 * c + 4] - keyStart[4 * c] + 255) / 256;
+	u32 size[MI_MAX_COLORS] = {}, need[MI_MAX_COLORS] = {};
+	for (u32 c = 0; c < numColors; ++c) { size[c] = keyStart[4 * c + 4] - keyStart[4 * c]; need[c] = (size[c] + 255) / 256; }
+	// Small worlds only (every colour fits one workgroup pass or two): the whole contact sweep of an iteration is one launch of the
+	// one-workgroup kernel.  On large worlds a colour step is bound by its dependent far-memory round trips (ids -> bodies -> store,
+	// ~4.7 us), not by the launch, and a single workgroup sweeping the small tail colours measured SLOWER than separate launches.
+	u32 firstTail = numColors;
+	{
+		bool allSmall = numColors >= 2;
+		for (u32 c = 0; c < numColors; ++c) if (size[c] > TAIL_MAX_MANIFOLDS) allSmall = false;
+		if (allSmall) firstTail = 0;
+	}
 	u32 numJointKernels = 0;
 	for (auto& js : w.joints) numJointKernels += js.colorStart.empty() ? 0 : (u32)js.colorStart.size() - 1;
 	if (!numColors && !serial && !numJointKernels) return;
@@ -369,11 +380,12 @@ static void runSolverSweep(World& w, u32 iters, u32 numColors)
 	World::SolveGraph& g = w.solveGraph;
 	if (!w.useGraph)
 	{
-		enqueueSolverSweep(w, iters, need, numColors, serial);
+		enqueueSolverSweep(w, iters, need, numColors, firstTail, serial);
 		return;
 	}
 	bool reuse = g.exec && g.numColors == numColors && g.iterations == iters && g.serial == serial && g.jointVersion == w.jointVersion && g.bufferVersion == w.bufferVersion;
-	for (u32 c = 0; reuse && c < numColors; ++c)
+	if (g.firstTail != firstTail) reuse = false;
+	for (u32 c = 0; reuse && c < numColors && c < g.firstTail; ++c)
 	{
 		// kernels grid-stride, so a cached grid stays correct; rebuild only when it is badly sized (> 2 passes or > 4x too wide)
 		if (need[c] > 2 * g.gridBlocks[c] || (g.gridBlocks[c] > 4 * std::max(need[c], 1u) && g.gridBlocks[c] > 8)) reuse = false;
@@ -384,10 +396,10 @@ static void runSolverSweep(World& w, u32 iters, u32 numColors)
 		if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
 		for (u32 c = 0; c < MI_MAX_COLORS; ++c) g.gridBlocks[c] = (c < numColors) ? std::max(1u, need[c] + need[c] / 4) : 0;
 		MI_CHECK(hipStreamBeginCapture(w.stream, hipStreamCaptureModeThreadLocal));
-		enqueueSolverSweep(w, iters, g.gridBlocks, numColors, serial);
+		enqueueSolverSweep(w, iters, g.gridBlocks, numColors, firstTail, serial);
 		MI_CHECK(hipStreamEndCapture(w.stream, &g.graph));
 		if (g.graph) MI_CHECK(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-		g.numColors = numColors; g.iterations = iters; g.serial = serial; g.jointVersion = w.jointVersion; g.bufferVersion = w.bufferVersion;
+		g.numColors = numColors; g.firstTail = firstTail; g.iterations = iters; g.serial = serial; g.jointVersion = w.jointVersion; g.bufferVersion = w.bufferVersion;
 		w.stats.numGraphBuilds++;
 	}
 	if (g.exec) MI_CHECK(hipGraphLaunch(g.exec, w.stream));

@@ -25,3 +25,11 @@ for i in range(steps): w.step_internal(s.dt)
 w.synchronize(); t1 = time.time()
 print("%s: %.3f ms/step  %.1f steps/s" % (name, (t1 - t0) / steps * 1e3, steps / (t1 - t0)))
 tr = w.transforms(); print("nan:", np.isnan(tr).any(), "minY %.2f maxY %.2f" % (tr[:, 1].min(), tr[:, 1].max()))
+slots, cs = w.schedule()
+import numpy as np
+print("colour sizes:", np.diff(cs.astype(np.int64))[:int(w.stats()["numColors"]) + 1].tolist(), "serial:", int(cs[65] - cs[64]))
+cog, inv = w.body_state()
+pairs, counts, contacts, bp = w.manifolds()
+act = counts > 0
+deg = np.bincount(np.concatenate([bp[act, 0], bp[act, 1]]), minlength=w.num_bodies + 1)[:w.num_bodies]
+print("body degree: max %d mean %.2f hist %s" % (deg.max(), deg.mean(), np.bincount(deg)[:24].tolist()))

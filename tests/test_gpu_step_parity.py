@@ -63,7 +63,8 @@ def test_follow_ragdolls_per_step(mi, oracle):
 
 def test_ragdolls_free_running_invariants(mi):
     """Config 4 free-running for 2 s: ragdoll dynamics are chaotic, so instead of trajectory parity the joints' own invariants are
-    checked on the device result: finite state, nothing below the ground, and every joint's two anchors stay together (< 3 cm)."""
+    checked on the device result: finite state, nothing below the ground, and every joint's two anchors stay together (< 6 cm;
+    the oracle itself peaks at 4.3-4.4 cm on this scene with either Gauss-Seidel order: Baumgarte beta 0.1, 30 iterations)."""
     from directx_renderer_kurth_amd import scenes
     scene = scenes.by_name("c4_small")
     g = scene.instantiate(mi.World())
@@ -85,7 +86,7 @@ def test_ragdolls_free_running_invariants(mi):
             pa = t[a, :3] + rot(t[a, 3:], pod[0:3]); pb = t[b, :3] + rot(t[b, 3:], pod[3:6])
             worst = max(worst, float(np.linalg.norm(pa - pb)))
     print("worst joint anchor separation after 120 steps: %.4f m" % worst)
-    assert worst < 0.03
+    assert worst < 0.06
 
 
 def test_physics_step_fixed_timestep(mi, oracle):
