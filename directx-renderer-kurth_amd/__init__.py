@@ -62,7 +62,7 @@ EXPORTED_SYMBOLS = [
     "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
     "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_apply_force_torque", "mi_set_velocity",
     "mi_set_transform", "mi_write_transforms", "mi_write_velocities", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
-    "mi_get_stats", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_debug_num_pairs", "mi_debug_read_pairs",
+    "mi_get_stats", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_debug_num_pairs", "mi_debug_read_pairs",
     "mi_debug_read_world_colliders", "mi_debug_num_manifold_slots", "mi_debug_read_manifolds", "mi_debug_num_colors", "mi_debug_read_schedule",
     "mi_debug_read_joint_order", "mi_debug_read_body_state",
 ]
@@ -248,6 +248,12 @@ class World:
         pose, vel, stream = C.c_void_p(), C.c_void_p(), C.c_void_p()
         self._check(self.lib.mi_device_pointers(self.w, C.byref(pose), C.byref(vel), C.byref(stream)))
         return pose.value, vel.value, stream.value
+
+    def state_to_device_buffers(self, pose_ptr, vel_ptr):
+        self._check(self.lib.mi_state_to_device_buffers(self.w, C.c_void_p(pose_ptr), C.c_void_p(vel_ptr)))
+
+    def state_from_device_buffers(self, pose_ptr, vel_ptr, mask_ptr):
+        self._check(self.lib.mi_state_from_device_buffers(self.w, C.c_void_p(pose_ptr), C.c_void_p(vel_ptr), C.c_void_p(mask_ptr)))
 
     # ---- inspection of the last internal step (parity tests) -------------------------------------------------------
     def pairs(self):

@@ -26,12 +26,19 @@ MI_DEV void boxToAABB(V3 lo, V3 hi, Q4 rot, V3 tr, V3& mn, V3& mx)
 }
 
 __global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
-	const float4* __restrict__ colStaticPose, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax)
+	const float4* __restrict__ colStaticPose, const uint8_t* __restrict__ simMask, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nc) return;
 	ColliderRec c = colLocal[i];
 	u32 type = colType(c), body = colBody(c);
+	if (body < nb && !simMask[body]) // body simulated by another GPU (spatial slabs): empty AABB, overlaps nothing
+	{
+		colWorld[i] = c;
+		aabbMin[i] = make_float4(MI_FLT_MAX, MI_FLT_MAX, MI_FLT_MAX, 0.f);
+		aabbMax[i] = make_float4(-MI_FLT_MAX, -MI_FLT_MAX, -MI_FLT_MAX, 0.f);
+		return;
+	}
 	const float4* P = (body < nb) ? (pose + 2 * body) : (colStaticPose + 2 * i);
 	V3 tpos = v3f4(P[0]);
 	Q4 trot = q4f4(P[1]);
@@ -99,17 +106,18 @@ void launch_build_colliders(World& w)
 {
 	if (!w.nc) return;
 	hipLaunchKernelGGL(k_build_colliders, dim3((w.nc + 255) / 256), dim3(256), 0, w.stream, w.nc, w.nb, w.colLocal.p, w.pose.p, w.colStaticPose.p,
-		w.colWorld.p, w.aabbMin.p, w.aabbMax.p);
+		w.simMask.p, w.colWorld.p, w.aabbMin.p, w.aabbMax.p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K8: gravity + force integration, world inertia.  140 B read + 104 B write per body.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, const float4* __restrict__ pose, const float4* __restrict__ bprops,
-	const float4* __restrict__ force, float4* __restrict__ vel, float4* __restrict__ cog, float4* __restrict__ invIw)
+	const float4* __restrict__ force, const uint8_t* __restrict__ simMask, float4* __restrict__ vel, float4* __restrict__ cog, float4* __restrict__ invIw)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > nb) return;
+	if (i < nb && !simMask[i]) return;
 	if (i == nb) // static dummy (physics.cpp:1279)
 	{
 		float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -149,17 +157,17 @@ __global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, cons
 void launch_integrate_forces(World& w, float dt)
 {
 	hipLaunchKernelGGL(k_integrate_forces, dim3((w.nb + 1 + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.force.p,
-		w.vel.p, w.cog.p, w.invIw.p);
+		w.simMask.p, w.vel.p, w.cog.p, w.invIw.p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K13: velocity integration.  Reads cog(16) + vel(32) + rot(16) + localCOG(16), writes pose(32) + clears accumulators.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_integrate_velocities(u32 nb, float dt, float4* __restrict__ pose, const float4* __restrict__ bprops,
-	const float4* __restrict__ vel, const float4* __restrict__ cog, float4* __restrict__ force)
+	const float4* __restrict__ vel, const float4* __restrict__ cog, const uint8_t* __restrict__ simMask, float4* __restrict__ force)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= nb) return;
+	if (i >= nb || !simMask[i]) return;
 	Q4 grot = q4f4(pose[2 * i + 1]);
 	V3 gpos = v3f4(cog[i]);
 	V3 v = v3f4(vel[2 * i]), wv = v3f4(vel[2 * i + 1]);
@@ -178,7 +186,7 @@ __global__ void __launch_bounds__(256) k_integrate_velocities(u32 nb, float dt, 
 void launch_integrate_velocities(World& w, float dt)
 {
 	if (!w.nb) return;
-	hipLaunchKernelGGL(k_integrate_velocities, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.vel.p, w.cog.p, w.force.p);
+	hipLaunchKernelGGL(k_integrate_velocities, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.vel.p, w.cog.p, w.simMask.p, w.force.p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

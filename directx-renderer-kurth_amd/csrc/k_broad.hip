@@ -58,7 +58,8 @@ __global__ void __launch_bounds__(256) k_cell_assign(u32 nc, u32 hashMask, const
 	float4 mn = aabbMin[i], mx = aabbMax[i];
 	float e = fmaxf(fmaxf(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
 	u32 h;
-	if (e > maxExtent) { h = hashMask + 1; } // large: sorts behind every grid cell
+	if (mn.x > mx.x) { h = hashMask + 2; }    // empty AABB (body simulated elsewhere): sorts last, never visited
+	else if (e > maxExtent) { h = hashMask + 1; } // large: sorts behind every grid cell
 	else { h = hashCell(packCell(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell)), hashMask); }
 	hashKey[i] = h;
 	sortIdx[i] = i;
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(256) k_gather_sorted(u32 nc, u32 hashMask, con
 		if (hPrev != h) cellStart[h] = t;
 		if (hNext != h) cellEnd[h] = t + 1;
 	}
-	else if (hPrev != h) { counters[CTR_FIRST_LARGE] = t; }
+	else if (hPrev != h) { counters[h == hashMask + 1 ? CTR_FIRST_LARGE : CTR_FIRST_INACTIVE] = t; }
 }
 
 // Overlapping partners of the collider at sorted position t.  Every pair is produced exactly once, as (A = this collider,
@@ -102,7 +103,9 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* 
 {
 	u32 t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= nc) return;
-	u32 firstLarge = min(counters[CTR_FIRST_LARGE], nc);
+	u32 nEnd = min(counters[CTR_FIRST_INACTIVE], nc);      // colliders behind this position have empty AABBs
+	u32 firstLarge = min(counters[CTR_FIRST_LARGE], nEnd);
+	if (t >= nEnd) { if (MODE == MODE_SLAB) pairCount[t] = 0; return; }
 	float4 amin = sMin[t], amax = sMax[t];
 	u32 me = __float_as_uint(amin.w);
 	u32 n = 0;
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* 
 				if (aabbOverlap(amin, amax, bmin, bmax)) EMIT(__float_as_uint(bmin.w))
 			}
 		}
-		for (u32 u = firstLarge; u < nc; ++u)
+		for (u32 u = firstLarge; u < nEnd; ++u)
 		{
 			float4 bmin = sMin[u], bmax = sMax[u];
 			if (aabbOverlap(amin, amax, bmin, bmax)) EMIT(__float_as_uint(bmin.w))
@@ -209,8 +212,8 @@ void launch_broadphase_count(World& w)
 	hipLaunchKernelGGL(k_max_extent, grid, block, 0, w.stream, nc, w.nb, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p);
 	hipLaunchKernelGGL(k_cell_assign, grid, block, 0, w.stream, nc, mask, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.hashKey.p, w.sortIdx.p);
 	prim_sort_pairs_u32(w, w.hashKey.p, w.hashKeySorted.p, w.sortIdx.p, w.sortIdxSorted.p, nc, log2ceil(H) + 1);
-	u32 ncAsFirstLarge = nc;
-	MI_CHECK(hipMemcpyAsync(w.dCounters.p + CTR_FIRST_LARGE, &ncAsFirstLarge, sizeof(u32), hipMemcpyHostToDevice, w.stream));
+	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_FIRST_LARGE, 0xFF, sizeof(u32), w.stream));    // "none": kernels clamp to nc
+	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_FIRST_INACTIVE, 0xFF, sizeof(u32), w.stream));
 	hipLaunchKernelGGL(k_gather_sorted, grid, block, 0, w.stream, nc, mask, w.hashKeySorted.p, w.sortIdxSorted.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p,
 		w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p);
 	w.pairSlab.ensure((size_t)nc * PAIR_SLAB, w.stream);

@@ -70,6 +70,7 @@ enum
 	CTR_NUM_ACTIVE = 9,     // append cursor of the active-manifold list
 	CTR_NUM_CONTACTS = 10,  // sum of contact counts over the active manifolds
 	CTR_PAIR_OVERFLOW = 11, // some collider has more broadphase partners than its slab holds
+	CTR_FIRST_INACTIVE = 12,// sorted position of the first collider whose body is simulated by another GPU
 	CTR_BUCKET_START = 16,  // 65 words: first slot of narrowphase bucket key b (tA*6+tB); [64] unused
 	CTR_KEY_START = 96,     // (MI_MAX_COLORS+1)*4 + 1 words: first schedule slot of key colour*4 + (4-count); last = numManifolds
 	CTR_WORDS = 512,
@@ -97,6 +98,7 @@ struct World
 	DevBuf<float4> pose, pose0, poseLerp, vel, bprops, force, cog, invIw;
 	DevBuf<ColliderRec> colLocal, colWorld;
 	DevBuf<float4> colStaticPose, aabbMin, aabbMax;
+	DevBuf<uint8_t> simMask;              // per body: 1 = simulated here (owned or ghost), 0 = lives on another GPU's slab
 	// broadphase
 	DevBuf<u32> hashKey, hashKeySorted, sortIdx, sortIdxSorted, cellStart, cellEnd, largeFlag, largeScan, largeList, pairCount, pairOffset;
 	DevBuf<u64> sCellKey; DevBuf<float4> sMin, sMax;

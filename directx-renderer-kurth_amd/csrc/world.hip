@@ -59,7 +59,7 @@ World::~World()
 		&mColor, &mKey, &mKeySorted, &mIdx, &mOrder, &dCounters };
 	for (auto b : u4) b->release();
 	colLocal.release(); colWorld.release(); sCellKey.release(); pairs.release(); pairsSorted.release(); manifolds.release(); bodyMask.release(); claim.release();
-	rowLambda.release(); rowIds.release(); tempStorage.release(); actIds.release(); epaList.release(); gjkSimplex.release(); pairSlab.release();
+	rowLambda.release(); rowIds.release(); tempStorage.release(); actIds.release(); epaList.release(); gjkSimplex.release(); pairSlab.release(); simMask.release();
 	for (auto& js : joints) { js.dPods.release(); js.dPairs.release(); js.dUpdate.release(); }
 	for (auto& e : stageEvents) if (e) (void)hipEventDestroy(e);
 	if (hCounters) (void)hipHostFree(hCounters);
@@ -253,6 +253,8 @@ void World::upload()
 	pose.ensure(2 * nb1, stream); pose0.ensure(2 * nb1, stream); poseLerp.ensure(2 * nb1, stream); vel.ensure(2 * nb1, stream);
 	bprops.ensure(5 * nb1, stream); force.ensure(2 * nb1, stream); cog.ensure(nb1, stream); invIw.ensure(3 * nb1, stream);
 	bodyMask.ensure(nb1, stream); claim.ensure(2 * nb1, stream);
+	simMask.ensure(nb1, stream);
+	MI_CHECK(hipMemsetAsync(simMask.p, 1, nb1, stream));
 	size_t ncap = std::max<size_t>(nc, 1);
 	colLocal.ensure(ncap, stream); colWorld.ensure(ncap, stream); colStaticPose.ensure(2 * ncap, stream); aabbMin.ensure(ncap, stream); aabbMax.ensure(ncap, stream);
 	hashKey.ensure(ncap, stream); hashKeySorted.ensure(ncap, stream); sortIdx.ensure(ncap, stream); sortIdxSorted.ensure(ncap, stream);
@@ -852,6 +854,28 @@ int mi_device_pointers(mi_world* world, void** pose, void** vel, void** stream)
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	W->upload();
 	if (pose) *pose = W->pose.p; if (vel) *vel = W->vel.p; if (stream) *stream = (void*)W->stream;
+	return W->lastError;
+}
+
+// ---- multi-GPU slabs: state hand-over in device memory (directx-renderer-kurth_amd/parallel.py drives the halo exchange) ----
+int mi_state_to_device_buffers(mi_world* world, void* dPose, void* dVel)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->upload();
+	if (!W->nb) return W->lastError;
+	MI_CHECK(hipMemcpyAsync(dPose, W->pose.p, sizeof(float4) * 2 * W->nb, hipMemcpyDeviceToDevice, W->stream));
+	MI_CHECK(hipMemcpyAsync(dVel, W->vel.p, sizeof(float4) * 2 * W->nb, hipMemcpyDeviceToDevice, W->stream));
+	MI_CHECK(hipStreamSynchronize(W->stream));
+	return W->lastError;
+}
+int mi_state_from_device_buffers(mi_world* world, const void* dPose, const void* dVel, const uint8_t* dMask)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->upload();
+	if (!W->nb) return W->lastError;
+	if (dPose) MI_CHECK(hipMemcpyAsync(W->pose.p, dPose, sizeof(float4) * 2 * W->nb, hipMemcpyDeviceToDevice, W->stream));
+	if (dVel) MI_CHECK(hipMemcpyAsync(W->vel.p, dVel, sizeof(float4) * 2 * W->nb, hipMemcpyDeviceToDevice, W->stream));
+	if (dMask) MI_CHECK(hipMemcpyAsync(W->simMask.p, dMask, W->nb, hipMemcpyDeviceToDevice, W->stream));
 	return W->lastError;
 }
 

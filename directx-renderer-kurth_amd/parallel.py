@@ -1,0 +1,191 @@
+"""Spatial slabs across the GPUs of one node with a ghost-body halo exchange (RCCL over xGMI via torch.distributed).
+
+The reference is a single process with no notion of this; the design is ours.
+
+* The world is cut into `world_size` slabs along one axis at body-count quantiles.  Rank r OWNS the bodies whose position lies in its
+  slab.  Every rank allocates ALL bodies (same indices everywhere — 1 M bodies are 100 MB of state in a 288 GB HBM), but simulates
+  only its owned bodies plus GHOST copies of the neighbours' bodies within `margin` of the cut; everything else is masked out on
+  the device (no AABB, no integration).
+* Once per step, before the step: each rank sends its owned bodies that lie within `margin` of a cut (pose + velocity, 64 B each,
+  plus index and a flag) to that neighbour with point-to-point send/recv — two messages per neighbour, no all-reduce on the data
+  path (xGMI links are point-to-point).  A body that crossed the cut is sent with flag MIGRATE: the receiver becomes its owner,
+  the sender keeps it as a ghost.  Ghosts that dropped out of the neighbour's message are masked out.
+* Contacts between an owned and a ghost body are generated and solved on both ranks from identical inputs; ghost results are
+  discarded at the next exchange (block-Jacobi coupling across the cut, Gauss-Seidel inside a slab).
+
+`HaloExchanger` is pure torch (CPU tensors + gloo in the tests, CUDA tensors + nccl on the GPUs); `SlabWorld` binds it to the HIP world.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+INACTIVE, OWNED, GHOST_LEFT, GHOST_RIGHT = 0, 1, 2, 3
+FLAG_GHOST, FLAG_MIGRATE = 0, 1
+
+
+def quantile_cuts(x, world_size):
+    """Cut positions (world_size - 1 values) giving equal body counts per slab."""
+    xs = np.sort(np.asarray(x, np.float64))
+    return [float(xs[(len(xs) * r) // world_size]) for r in range(1, world_size)]
+
+
+class HaloExchanger:
+    """Ownership + ghost bookkeeping on flat state tensors.
+
+    pose: [N, 8] float32 (pos.xyz, 0, quat), vel: [N, 8] float32 (v.xyz, invMass, w.xyz, 0), code: [N] int8 in {INACTIVE, OWNED, GHOST_*}.
+    """
+
+    def __init__(self, rank, world_size, cuts, axis=0, margin=3.0, device="cpu", group=None, comm_on_cpu=False):
+        self.rank, self.world_size, self.axis, self.margin, self.device, self.group = rank, world_size, axis, float(margin), device, group
+        self.comm_device = "cpu" if comm_on_cpu else device  # gloo rehearsals of GPU worlds stage the messages through host memory
+        self.lo = cuts[rank - 1] if rank > 0 else -float("inf")
+        self.hi = cuts[rank] if rank < world_size - 1 else float("inf")
+        self.bytes_sent = 0
+
+    def initial_code(self, pose):
+        x = pose[:, self.axis]
+        code = torch.zeros(pose.shape[0], dtype=torch.int8, device=pose.device)
+        code[(x >= self.lo) & (x < self.hi)] = OWNED
+        # ghosts of the initial configuration: what the neighbours would send in their first exchange
+        code[(x >= self.hi) & (x < self.hi + self.margin)] = GHOST_RIGHT
+        code[(x < self.lo) & (x >= self.lo - self.margin)] = GHOST_LEFT
+        return code
+
+    def _pack(self, pose, vel, code, to_right):
+        x = pose[:, self.axis]
+        owned = code == OWNED
+        if to_right:
+            band = owned & (x >= self.hi - self.margin)
+            migrate = owned & (x >= self.hi)
+        else:
+            band = owned & (x < self.lo + self.margin)
+            migrate = owned & (x < self.lo)
+        idx = torch.nonzero(band, as_tuple=False).flatten()
+        meta = torch.stack([idx.to(torch.int32), migrate[idx].to(torch.int32)], dim=1).contiguous()
+        payload = torch.cat([pose[idx], vel[idx]], dim=1).contiguous()
+        return idx, migrate, meta, payload
+
+    def exchange(self, pose, vel, code):
+        """In-place update of pose/vel/code.  Collective over the group (neighbour point-to-point only)."""
+        left = self.rank - 1 if self.rank > 0 else None
+        right = self.rank + 1 if self.rank < self.world_size - 1 else None
+        send = {}
+        for nb, to_right in ((left, False), (right, True)):
+            if nb is not None:
+                send[nb] = self._pack(pose, vel, code, to_right)
+        # 1) sizes
+        cd = self.comm_device
+        counts_out = {nb: torch.tensor([s[2].shape[0]], dtype=torch.int64, device=cd) for nb, s in send.items()}
+        counts_in = {nb: torch.zeros(1, dtype=torch.int64, device=cd) for nb in send}
+        ops = []
+        for nb in send:
+            ops.append(dist.P2POp(dist.isend, counts_out[nb], nb, group=self.group))
+            ops.append(dist.P2POp(dist.irecv, counts_in[nb], nb, group=self.group))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        # 2) payloads
+        recv = {}
+        ops = []
+        for nb, (idx, migrate, meta, payload) in send.items():
+            n_in = int(counts_in[nb].item())
+            recv[nb] = (torch.zeros((n_in, 2), dtype=torch.int32, device=cd), torch.zeros((n_in, 16), dtype=torch.float32, device=cd))
+            if meta.shape[0]:
+                ops.append(dist.P2POp(dist.isend, meta.to(cd), nb, group=self.group))
+                ops.append(dist.P2POp(dist.isend, payload.to(cd), nb, group=self.group))
+                self.bytes_sent += meta.numel() * 4 + payload.numel() * 4
+            if n_in:
+                ops.append(dist.P2POp(dist.irecv, recv[nb][0], nb, group=self.group))
+                ops.append(dist.P2POp(dist.irecv, recv[nb][1], nb, group=self.group))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        # 3) apply: bodies I migrated out become ghosts of that neighbour (their state here is the freshest there is)
+        for nb, (idx, migrate, meta, payload) in send.items():
+            code[migrate] = GHOST_RIGHT if nb == right else GHOST_LEFT
+        for nb, (meta, payload) in recv.items():
+            meta, payload = meta.to(self.device), payload.to(self.device)
+            ghost_code = GHOST_RIGHT if nb == right else GHOST_LEFT
+            stale = code == ghost_code
+            if meta.shape[0]:
+                idx = meta[:, 0].to(torch.int64)
+                keep = torch.zeros_like(stale)
+                keep[idx] = True
+                # a ghost I just created by migrating a body out is not in the neighbour's message yet: keep it this step
+                mig_out = send[nb][1]
+                stale = stale & ~keep & ~mig_out
+                code[stale] = INACTIVE
+                pose[idx] = payload[:, :8]
+                vel[idx] = payload[:, 8:]
+                new_code = torch.where(meta[:, 1] == FLAG_MIGRATE, torch.tensor(OWNED, dtype=torch.int8, device=self.device),
+                                       torch.tensor(ghost_code, dtype=torch.int8, device=self.device))
+                code[idx] = new_code
+            else:
+                code[stale & ~send[nb][1]] = INACTIVE
+        return pose, vel, code
+
+
+class SlabWorld:
+    """One HIP world per rank; same interface subset as `World` for bench.py (step_internal / stats / synchronize / transforms)."""
+
+    def __init__(self, scene, device, rank, world_size, axis=0, margin=3.0, comm_on_cpu=False):
+        import directx_renderer_kurth_amd as mi
+        self.rank, self.world_size, self.scene = rank, world_size, scene
+        self.dev = torch.device("cuda", device)
+        self.world = scene.instantiate(mi.World(device=device))
+        n = scene.num_bodies
+        x0 = np.array([b[0][axis] for b in scene.bodies], np.float64)
+        self.exchanger = HaloExchanger(rank, world_size, quantile_cuts(x0, world_size), axis=axis, margin=margin, device=self.dev, comm_on_cpu=comm_on_cpu)
+        self.pose = torch.zeros((n, 8), dtype=torch.float32, device=self.dev)
+        self.vel = torch.zeros((n, 8), dtype=torch.float32, device=self.dev)
+        self.mask = torch.zeros(n, dtype=torch.uint8, device=self.dev)
+        self.world.state_to_device_buffers(self.pose.data_ptr(), self.vel.data_ptr())
+        self.code = self.exchanger.initial_code(self.pose)
+        self._push()
+
+    def _push(self):
+        self.mask.copy_((self.code != INACTIVE).to(torch.uint8))
+        torch.cuda.current_stream(self.dev).synchronize()
+        self.world.state_from_device_buffers(self.pose.data_ptr(), self.vel.data_ptr(), self.mask.data_ptr())
+
+    def step_internal(self, dt, iterations=30):
+        self.world.state_to_device_buffers(self.pose.data_ptr(), self.vel.data_ptr())  # synchronises the world's stream
+        self.exchanger.exchange(self.pose, self.vel, self.code)
+        self._push()
+        self.world.step_internal(dt, iterations)
+
+    def synchronize(self):
+        self.world.synchronize()
+
+    def enable_stage_timing(self, on=True):
+        self.world.enable_stage_timing(on)
+
+    def stats(self):
+        return self.world.stats()
+
+    def gather_stats(self, acc):
+        """Sum the count-like statistics over ranks (stage times: max), in place on rank 0's accumulator."""
+        keys = sorted(acc.keys())
+        t = torch.tensor([acc[k] for k in keys], dtype=torch.float64, device=self.dev)
+        tmax = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        for i, k in enumerate(keys):
+            acc[k] = float(tmax[i]) if (k.startswith("ms") or k in ("numColors", "numRigidBodies", "numColliders", "numInternalSteps", "numGraphBuilds", "coloringRounds")) else float(t[i])
+
+    def owned_mask(self):
+        return (self.code == OWNED).cpu().numpy()
+
+    def transforms(self, which=1):
+        """Global transforms assembled from every rank's owned bodies (collective)."""
+        t = torch.as_tensor(self.world.transforms(which), device=self.dev)
+        own = (self.code == OWNED).to(torch.float32)[:, None]
+        t = t * own
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def velocities(self):
+        v = torch.as_tensor(self.world.velocities(), device=self.dev)
+        v = v * (self.code == OWNED).to(torch.float32)[:, None]
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        return v.cpu().numpy()

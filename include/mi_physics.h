@@ -132,6 +132,13 @@ uint32_t mi_num_colliders(mi_world* w);
  * {v.xyz, invMass},{w.xyz,0}.  The caller may read/write them on `stream` between steps (ghost-body refresh). */
 int mi_device_pointers(mi_world* w, void** pose, void** vel, void** stream);
 
+/* Spatial-slab runs (one world per GPU holding ALL bodies, each simulating its slab + ghosts): copy the whole pose / velocity arrays
+ * (layout as mi_device_pointers) to / from caller-owned DEVICE buffers, and set the per-body simulate mask (1 byte per body, device
+ * memory; 0 = body lives on another GPU: no AABB, no integration).  The halo exchange itself (RCCL send/recv of boundary bodies) is
+ * host-side logic above this ABI; the reference has no counterpart (single process). */
+int mi_state_to_device_buffers(mi_world* w, void* dPose, void* dVel);
+int mi_state_from_device_buffers(mi_world* w, const void* dPose, const void* dVel, const uint8_t* dMask);
+
 /* ---- inspection of the last internal step (parity tests; mirrors the arrays of physics.cpp:1207-1228) ---------------- */
 uint32_t mi_debug_num_pairs(mi_world* w);
 int mi_debug_read_pairs(mi_world* w, uint32_t* outPairs2);                              /* broadphase overlaps, (A,B) collider indices */
