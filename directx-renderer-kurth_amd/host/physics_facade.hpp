@@ -1,0 +1,269 @@
+// physics_facade.hpp — header-only C++ host side over the C-ABI (include/mi_physics.h) that keeps the reference's call shapes for the
+// rigid-body path, so engine code that today says
+//
+//     auto e = scene.createEntity("box").addComponent<transform_component>(pos, rot)
+//                   .addComponent<collider_component>(collider_component::asOBB(box, material))
+//                   .addComponent<rigid_body_component>(false, 1.f);
+//     auto h = addHingeConstraintFromGlobalPoints(a, b, anchor, axis, -0.5f, 0.5f);
+//     getConstraint(scene, h).maxMotorTorque = 200.f;
+//     physicsStep(scene, arena, timer, settings, dt);
+//
+// compiles against this header with the same statements (reference: physics.h:108-157, 209-264, 382-405; rigid_body.h:18-46;
+// scene.h:38-84).  What differs, and why:
+//   * game_scene here owns an mi_world (device memory + one HIP stream) instead of an EnTT registry; entities are light handles.
+//   * getConstraint() returns a write-back proxy instead of T&: the POD lives in device-side tables, so the proxy reads it on
+//     construction and stores it when it goes out of scope (same statement syntax for field writes).
+//   * memory_arena& is accepted and ignored (per-step arrays live in the world's device arena).
+//   * Errors surface as mi::physics_error instead of ASSERT/__debugbreak (pch.h:33-34).
+// Nothing here computes physics; there is no CPU path.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "mi_physics.h"
+
+namespace mi
+{
+	struct physics_error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+	struct vec3 { float x = 0, y = 0, z = 0; vec3() = default; vec3(float x_, float y_, float z_) : x(x_), y(y_), z(z_) {} };
+	struct quat { float x = 0, y = 0, z = 0, w = 1; quat() = default; quat(float x_, float y_, float z_, float w_) : x(x_), y(y_), z(z_), w(w_) {} };
+
+	// bounding volumes as the collider factories take them (bounding_volumes.h:25-148)
+	struct bounding_sphere { vec3 center; float radius; };
+	struct bounding_capsule { vec3 positionA, positionB; float radius; };
+	struct bounding_cylinder { vec3 positionA, positionB; float radius; };
+	struct bounding_box { vec3 minCorner, maxCorner; static bounding_box fromCenterRadius(vec3 c, vec3 r) { return { { c.x - r.x, c.y - r.y, c.z - r.z }, { c.x + r.x, c.y + r.y, c.z + r.z } }; } };
+	struct bounding_oriented_box { quat rotation; vec3 center, radius; };
+
+	struct physics_material { float restitution, friction, density; }; // physics.h:40-47 without the sound tag
+
+	struct transform_component { vec3 position; quat rotation; transform_component(vec3 p = {}, quat r = {}) : position(p), rotation(r) {} };
+
+	// collider_component::as*(shape, material), physics.h:108-157
+	struct collider_component
+	{
+		uint32_t type = MI_COLLIDER_SPHERE; float shape[10] = {}; physics_material material{};
+		static collider_component asSphere(bounding_sphere s, physics_material m) { collider_component c; c.type = MI_COLLIDER_SPHERE; c.set({ s.center.x, s.center.y, s.center.z, s.radius }); c.material = m; return c; }
+		static collider_component asCapsule(bounding_capsule s, physics_material m) { collider_component c; c.type = MI_COLLIDER_CAPSULE; c.set({ s.positionA.x, s.positionA.y, s.positionA.z, s.positionB.x, s.positionB.y, s.positionB.z, s.radius }); c.material = m; return c; }
+		static collider_component asCylinder(bounding_cylinder s, physics_material m) { collider_component c; c.type = MI_COLLIDER_CYLINDER; c.set({ s.positionA.x, s.positionA.y, s.positionA.z, s.positionB.x, s.positionB.y, s.positionB.z, s.radius }); c.material = m; return c; }
+		static collider_component asAABB(bounding_box b, physics_material m) { collider_component c; c.type = MI_COLLIDER_AABB; c.set({ b.minCorner.x, b.minCorner.y, b.minCorner.z, b.maxCorner.x, b.maxCorner.y, b.maxCorner.z }); c.material = m; return c; }
+		static collider_component asOBB(bounding_oriented_box b, physics_material m) { collider_component c; c.type = MI_COLLIDER_OBB; c.set({ b.rotation.x, b.rotation.y, b.rotation.z, b.rotation.w, b.center.x, b.center.y, b.center.z, b.radius.x, b.radius.y, b.radius.z }); c.material = m; return c; }
+	private:
+		void set(std::initializer_list<float> v) { int i = 0; for (float f : v) shape[i++] = f; }
+	};
+
+	// rigid_body_component(bool kinematic, float gravityFactor = 1, float linearDamping = .4, float angularDamping = .4), rigid_body.h:21
+	struct rigid_body_component
+	{
+		bool kinematic = false; float gravityFactor = 1.f, linearDamping = 0.4f, angularDamping = 0.4f;
+		rigid_body_component(bool k = false, float g = 1.f, float l = 0.4f, float a = 0.4f) : kinematic(k), gravityFactor(g), linearDamping(l), angularDamping(a) {}
+	};
+
+	// physics_settings, physics.h:382-397 (callbacks: out of scope)
+	struct physics_settings
+	{
+		bool fixedFrameRate = true; uint32_t frameRate = 120; uint32_t maxPhysicsIterationsPerFrame = 4; uint32_t numRigidSolverIterations = 30;
+		uint32_t numClothVelocityIterations = 0, numClothPositionIterations = 1, numClothDriftIterations = 0;
+		bool simdBroadPhase = true, simdNarrowPhase = true, simdConstraintSolver = true;
+	};
+
+	struct memory_arena {}; // accepted and ignored by physicsStep
+
+	// Joint PODs: byte-identical to the reference structs (constraints.h:73-80,129-135,175-183,229-257,346-380,497-520).
+	struct distance_constraint { vec3 localAnchorA, localAnchorB; float globalLength; };
+	struct ball_constraint { vec3 localAnchorA, localAnchorB; };
+	struct fixed_constraint { quat initialInvRotationDifference; vec3 localAnchorA, localAnchorB; };
+	enum constraint_motor_type : uint32_t { constraint_velocity_motor = MI_MOTOR_VELOCITY, constraint_position_motor = MI_MOTOR_POSITION };
+	struct hinge_constraint
+	{
+		vec3 localAnchorA, localAnchorB, localHingeAxisA, localHingeAxisB;
+		float minRotationLimit, maxRotationLimit, maxMotorTorque;
+		constraint_motor_type motorType; union { float motorVelocity; float motorTargetAngle; };
+		vec3 localHingeTangentA, localHingeBitangentA, localHingeTangentB;
+	};
+	struct cone_twist_constraint
+	{
+		vec3 localAnchorA, localAnchorB, localLimitAxisA, localLimitAxisB, localLimitTangentA, localLimitBitangentA, localLimitTangentB;
+		float swingLimit, twistLimit;
+		constraint_motor_type swingMotorType; union { float swingMotorVelocity; float swingMotorTargetAngle; }; float maxSwingMotorTorque, swingMotorAxis;
+		constraint_motor_type twistMotorType; union { float twistMotorVelocity; float twistMotorTargetAngle; }; float maxTwistMotorTorque;
+	};
+	struct slider_constraint
+	{
+		quat initialInvRotationDifference; vec3 localAnchorA, localAnchorB, localAxisA;
+		float negDistanceLimit, posDistanceLimit, maxMotorForce;
+		constraint_motor_type motorType; union { float motorVelocity; float motorTargetDistance; };
+	};
+	static_assert(sizeof(distance_constraint) == 28 && sizeof(ball_constraint) == 24 && sizeof(fixed_constraint) == 40, "POD layout");
+	static_assert(sizeof(hinge_constraint) == 104 && sizeof(cone_twist_constraint) == 120 && sizeof(slider_constraint) == 72, "POD layout");
+
+	template <typename T> struct constraint_type_of;
+	template <> struct constraint_type_of<distance_constraint> { static constexpr uint32_t value = MI_CONSTRAINT_DISTANCE; };
+	template <> struct constraint_type_of<ball_constraint> { static constexpr uint32_t value = MI_CONSTRAINT_BALL; };
+	template <> struct constraint_type_of<fixed_constraint> { static constexpr uint32_t value = MI_CONSTRAINT_FIXED; };
+	template <> struct constraint_type_of<hinge_constraint> { static constexpr uint32_t value = MI_CONSTRAINT_HINGE; };
+	template <> struct constraint_type_of<cone_twist_constraint> { static constexpr uint32_t value = MI_CONSTRAINT_CONE_TWIST; };
+	template <> struct constraint_type_of<slider_constraint> { static constexpr uint32_t value = MI_CONSTRAINT_SLIDER; };
+
+	template <typename T> struct constraint_handle { uint32_t id = 0xFFFFFFFFu; };
+	using distance_constraint_handle = constraint_handle<distance_constraint>;
+	using ball_constraint_handle = constraint_handle<ball_constraint>;
+	using fixed_constraint_handle = constraint_handle<fixed_constraint>;
+	using hinge_constraint_handle = constraint_handle<hinge_constraint>;
+	using cone_twist_constraint_handle = constraint_handle<cone_twist_constraint>;
+	using slider_constraint_handle = constraint_handle<slider_constraint>;
+
+	struct game_scene;
+
+	// scene_entity: a light handle (scene.h:38-84).  Colliders added before the rigid body are held back until either the body is
+	// added (they become its colliders and its mass properties are recomputed, rigid_body.cpp:29-81) or the first step (they become
+	// static colliders, physics.cpp:667-671).
+	struct scene_entity
+	{
+		game_scene* scene = nullptr; uint32_t index = 0xFFFFFFFFu;
+		template <typename T, typename... Args> scene_entity& addComponent(Args&&... args);
+		uint32_t body() const;
+		transform_component transform() const; // transform_component after the last physicsStep (interpolated)
+		vec3 linearVelocity() const;
+	};
+
+	struct game_scene
+	{
+		struct entity_record { transform_component transform; uint32_t body = MI_STATIC_BODY; std::vector<collider_component> pending; std::vector<uint32_t> colliders; };
+
+		explicit game_scene(int device = -1)
+		{
+			mi_world_desc d{}; d.device = device;
+			world = mi_world_create(&d);
+			if (!world) throw physics_error(std::string("mi_world_create: ") + mi_last_error(nullptr));
+		}
+		~game_scene() { if (world) mi_world_destroy(world); }
+		game_scene(const game_scene&) = delete; game_scene& operator=(const game_scene&) = delete;
+
+		scene_entity createEntity(const char* /*name*/ = nullptr) { entities.emplace_back(); return scene_entity{ this, (uint32_t)entities.size() - 1 }; }
+
+		void check(int status, const char* what) const { if (status != MI_OK) throw physics_error(std::string(what) + ": " + mi_last_error(world)); }
+		uint32_t checkId(uint32_t id, const char* what) const { if (id == 0xFFFFFFFFu) throw physics_error(std::string(what) + ": " + mi_last_error(world)); return id; }
+
+		void flushStaticColliders()
+		{
+			for (auto& e : entities)
+			{
+				if (e.body != MI_STATIC_BODY) continue;
+				for (auto& c : e.pending)
+				{
+					mi_material m{ c.material.restitution, c.material.friction, c.material.density };
+					e.colliders.push_back(checkId(mi_add_static_collider(world, c.type, c.shape, &m, &e.transform.position.x, &e.transform.rotation.x), "mi_add_static_collider"));
+				}
+				e.pending.clear();
+			}
+		}
+
+		mi_world* world = nullptr;
+		std::vector<entity_record> entities;
+	};
+
+	template <typename T, typename... Args> inline scene_entity& scene_entity::addComponent(Args&&... args)
+	{
+		auto& e = scene->entities[index];
+		if constexpr (std::is_same_v<T, transform_component>) { e.transform = transform_component(std::forward<Args>(args)...); }
+		else if constexpr (std::is_same_v<T, collider_component>)
+		{
+			collider_component c(std::forward<Args>(args)...);
+			if (e.body == MI_STATIC_BODY) e.pending.push_back(c);
+			else
+			{
+				mi_material m{ c.material.restitution, c.material.friction, c.material.density };
+				e.colliders.push_back(scene->checkId(mi_add_collider(scene->world, e.body, c.type, c.shape, &m), "mi_add_collider"));
+			}
+		}
+		else if constexpr (std::is_same_v<T, rigid_body_component>)
+		{
+			rigid_body_component rb(std::forward<Args>(args)...);
+			e.body = scene->checkId(mi_add_body(scene->world, rb.kinematic, rb.gravityFactor, rb.linearDamping, rb.angularDamping, &e.transform.position.x, &e.transform.rotation.x), "mi_add_body");
+			for (auto& c : e.pending)
+			{
+				mi_material m{ c.material.restitution, c.material.friction, c.material.density };
+				e.colliders.push_back(scene->checkId(mi_add_collider(scene->world, e.body, c.type, c.shape, &m), "mi_add_collider"));
+			}
+			e.pending.clear();
+		}
+		else static_assert(sizeof(T) == 0, "component type not on the rigid-body path");
+		return *this;
+	}
+
+	inline uint32_t scene_entity::body() const
+	{
+		uint32_t b = scene->entities[index].body;
+		if (b == MI_STATIC_BODY) throw physics_error("entity has no rigid_body_component");
+		return b;
+	}
+
+	inline transform_component scene_entity::transform() const
+	{
+		auto& e = scene->entities[index];
+		if (e.body == MI_STATIC_BODY) return e.transform;
+		uint32_t n = e.body + 1; std::vector<float> t(7 * (size_t)n);
+		scene->check(mi_read_transforms(scene->world, 0, t.data(), n), "mi_read_transforms");
+		const float* p = &t[7 * (size_t)e.body];
+		return transform_component({ p[0], p[1], p[2] }, { p[3], p[4], p[5], p[6] });
+	}
+
+	inline vec3 scene_entity::linearVelocity() const
+	{
+		uint32_t n = body() + 1; std::vector<float> v(6 * (size_t)n);
+		scene->check(mi_read_velocities(scene->world, v.data(), n), "mi_read_velocities");
+		return { v[6 * (size_t)(n - 1)], v[6 * (size_t)(n - 1) + 1], v[6 * (size_t)(n - 1) + 2] };
+	}
+
+	// ---- add*ConstraintFrom{Local,Global}Points, physics.h:209-235
+	inline distance_constraint_handle addDistanceConstraintFromLocalPoints(scene_entity& a, scene_entity& b, vec3 localAnchorA, vec3 localAnchorB, float distance)
+	{ return { a.scene->checkId(mi_add_distance_constraint_local(a.scene->world, a.body(), b.body(), &localAnchorA.x, &localAnchorB.x, distance), "addDistanceConstraint") }; }
+	inline distance_constraint_handle addDistanceConstraintFromGlobalPoints(scene_entity& a, scene_entity& b, vec3 globalAnchorA, vec3 globalAnchorB)
+	{ return { a.scene->checkId(mi_add_distance_constraint_global(a.scene->world, a.body(), b.body(), &globalAnchorA.x, &globalAnchorB.x), "addDistanceConstraint") }; }
+	inline ball_constraint_handle addBallConstraintFromLocalPoints(scene_entity& a, scene_entity& b, vec3 localAnchorA, vec3 localAnchorB)
+	{ return { a.scene->checkId(mi_add_ball_constraint_local(a.scene->world, a.body(), b.body(), &localAnchorA.x, &localAnchorB.x), "addBallConstraint") }; }
+	inline ball_constraint_handle addBallConstraintFromGlobalPoints(scene_entity& a, scene_entity& b, vec3 globalAnchor)
+	{ return { a.scene->checkId(mi_add_ball_constraint_global(a.scene->world, a.body(), b.body(), &globalAnchor.x), "addBallConstraint") }; }
+	inline fixed_constraint_handle addFixedConstraintFromGlobalPoints(scene_entity& a, scene_entity& b, vec3 globalAnchor)
+	{ return { a.scene->checkId(mi_add_fixed_constraint_global(a.scene->world, a.body(), b.body(), &globalAnchor.x), "addFixedConstraint") }; }
+	inline hinge_constraint_handle addHingeConstraintFromGlobalPoints(scene_entity& a, scene_entity& b, vec3 globalAnchor, vec3 globalHingeAxis, float minLimit = 1.f, float maxLimit = -1.f)
+	{ return { a.scene->checkId(mi_add_hinge_constraint_global(a.scene->world, a.body(), b.body(), &globalAnchor.x, &globalHingeAxis.x, minLimit, maxLimit), "addHingeConstraint") }; }
+	inline cone_twist_constraint_handle addConeTwistConstraintFromGlobalPoints(scene_entity& a, scene_entity& b, vec3 globalAnchor, vec3 globalAxis, float swingLimit, float twistLimit)
+	{ return { a.scene->checkId(mi_add_cone_twist_constraint_global(a.scene->world, a.body(), b.body(), &globalAnchor.x, &globalAxis.x, swingLimit, twistLimit), "addConeTwistConstraint") }; }
+	inline slider_constraint_handle addSliderConstraintFromGlobalPoints(scene_entity& a, scene_entity& b, vec3 globalAnchor, vec3 globalAxis, float minLimit = 1.f, float maxLimit = -1.f)
+	{ return { a.scene->checkId(mi_add_slider_constraint_global(a.scene->world, a.body(), b.body(), &globalAnchor.x, &globalAxis.x, minLimit, maxLimit), "addSliderConstraint") }; }
+
+	// ---- getConstraint(scene, handle), physics.h:248-253: write-back proxy (see the header comment)
+	template <typename T> struct constraint_ref
+	{
+		constraint_ref(game_scene& s, uint32_t id_) : scene(s), id(id_) { scene.check(mi_constraint_get(scene.world, constraint_type_of<T>::value, id, &value), "getConstraint"); std::memcpy(&loaded, &value, sizeof(T)); }
+		~constraint_ref() { if (std::memcmp(&loaded, &value, sizeof(T)) != 0) mi_constraint_set(scene.world, constraint_type_of<T>::value, id, &value); }
+		constraint_ref(const constraint_ref&) = delete;
+		T* operator->() { return &value; }
+		T& operator*() { return value; }
+		game_scene& scene; uint32_t id; T value, loaded;
+	};
+	template <typename T> inline constraint_ref<T> getConstraint(game_scene& scene, constraint_handle<T> handle) { return constraint_ref<T>(scene, handle.id); }
+	template <typename T> inline void deleteConstraint(game_scene& scene, constraint_handle<T> handle) { scene.check(mi_delete_constraint(scene.world, constraint_type_of<T>::value, handle.id), "deleteConstraint"); }
+	inline void deleteAllConstraints(game_scene& scene) { scene.check(mi_delete_all_constraints(scene.world), "deleteAllConstraints"); }
+
+	// ---- void physicsStep(game_scene&, memory_arena&, float& timer, const physics_settings&, float dt), physics.h:405
+	inline void physicsStep(game_scene& scene, memory_arena& /*arena*/, float& timer, const physics_settings& settings, float dt)
+	{
+		scene.flushStaticColliders();
+		mi_physics_settings s{};
+		s.fixedFrameRate = settings.fixedFrameRate; s.frameRate = settings.frameRate; s.maxPhysicsIterationsPerFrame = settings.maxPhysicsIterationsPerFrame;
+		s.numRigidSolverIterations = settings.numRigidSolverIterations;
+		s.numClothVelocityIterations = settings.numClothVelocityIterations; s.numClothPositionIterations = settings.numClothPositionIterations; s.numClothDriftIterations = settings.numClothDriftIterations;
+		s.simdBroadPhase = settings.simdBroadPhase; s.simdNarrowPhase = settings.simdNarrowPhase; s.simdConstraintSolver = settings.simdConstraintSolver;
+		scene.check(mi_step(scene.world, &timer, &s, dt), "physicsStep");
+	}
+}
