@@ -53,8 +53,21 @@ __global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const C
 			mn = center - v3s(r); mx = center + v3s(r);
 			o.a = make_float4(center.x, center.y, center.z, r);
 		} break;
+		case MI_CYLINDER: // tight extents, physics.cpp:699-720
+		{
+			V3 posA = trot * v3(c.a.x, c.a.y, c.a.z) + tpos;
+			V3 posB = trot * v3(c.a.w, c.b.x, c.b.y) + tpos;
+			float r = c.b.z;
+			V3 a = posB - posA;
+			float aa = dot(a, a);
+			float x = 1.f - a.x * a.x / aa, y = 1.f - a.y * a.y / aa, z = 1.f - a.z * a.z / aa;
+			x = sqrtf(fmaxf(0.f, x)); y = sqrtf(fmaxf(0.f, y)); z = sqrtf(fmaxf(0.f, z));
+			V3 e = r * v3(x, y, z);
+			mn = vmin(posA - e, posB - e); mx = vmax(posA + e, posB + e);
+			o.a = make_float4(posA.x, posA.y, posA.z, posB.x);
+			o.b = make_float4(posB.y, posB.z, r, 0.f);
+		} break;
 		case MI_CAPSULE:
-		case MI_CYLINDER: // cylinders are stored but their pair kernels are not built yet (they never reach the narrowphase)
 		{
 			V3 posA = trot * v3(c.a.x, c.a.y, c.a.z) + tpos;
 			V3 posB = trot * v3(c.a.w, c.b.x, c.b.y) + tpos;

@@ -1,8 +1,8 @@
 // Narrowphase: prune / classify / bucket (reference collision_narrow.cpp:2346-2453), then one branch-uniform kernel family per
 // group of type pairs: closed forms (:374-612, :1074-1140), box-box SAT + Sutherland-Hodgman clipping (:1179-1527) and
-// GJK + EPA for capsule vs box (:705-790, collision_gjk.{h,cpp}, collision_epa.{h,cpp}).  One thread per candidate pair; every
-// pair writes a 96-byte ManifoldRec (count 0 = no collision) so contact generation needs no atomics and keeps pair order.
-// Hull pairs and cylinder pairs are not built (SURVEY §8 a19 / out of the BASELINE configs).
+// GJK + EPA for capsule / cylinder vs box and cylinder vs cylinder (:705-790, :821-1043, collision_gjk.{h,cpp}, collision_epa.{h,cpp}).
+// One thread per candidate pair; every pair writes a 96-byte ManifoldRec (count 0 = no collision) so contact generation needs no
+// atomics and keeps pair order.  Hull pairs are not built.
 #include "world.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
@@ -13,7 +13,7 @@ void prim_sort_pairs_u32_u64(World& w, const u32* kin, u32* kout, const u64* vin
 
 struct Man { V3 n; float4 p[4]; u32 count; };
 
-MI_DEV bool typeSupported(u32 t) { return t == MI_SPHERE || t == MI_CAPSULE || t == MI_AABB || t == MI_OBB; }
+MI_DEV bool typeSupported(u32 t) { return t <= MI_OBB; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K5: prune + classify.  Reads the 16-B tag quarter of both colliders.
@@ -150,7 +150,39 @@ MI_DEV bool sphereObb(Sphere s, Obb o, Man& m) // :480-494
 	}
 	return false;
 }
-MI_DEV bool capsuleCapsule(Capsule a, Capsule b, Man& m) // :523-612
+MI_DEV bool sphereCylinder(Sphere s, Capsule c, Man& m) // :408-449 (a cylinder is stored as {A, B, r} like a capsule)
+{
+	V3 ab = c.b - c.a;
+	float t = dot(s.c - c.a, ab) / sqlen(ab);
+	if (t >= 0.f && t <= 1.f)
+	{
+		Sphere s2; s2.c = lerp(c.a, c.b, t); s2.r = c.r;
+		return sphereSphere(s, s2, m);
+	}
+	V3 p = (t <= 0.f) ? c.a : c.b;
+	V3 up = (t <= 0.f) ? -ab : ab;
+	V3 projectedDirToCenter = normalize(cross(cross(up, s.c - p), up));
+	V3 endA = p + projectedDirToCenter * c.r;
+	V3 endB = p - projectedDirToCenter * c.r;
+	V3 closestToSphere = closestPointSegment(s.c, endA, endB);
+	V3 normal = closestToSphere - s.c;
+	float sq = sqlen(normal);
+	if (sq <= s.r * s.r)
+	{
+		float distance;
+		if (sq == 0.f) { distance = 0.f; m.n = -normalize(up); }
+		else { distance = sqrtf(sq); m.n = normal / distance; }
+		m.count = 1;
+		float depth = s.r - distance;
+		V3 pt = closestToSphere + 0.5f * depth * normal; // scales the un-normalised normal, as :445 does
+		m.p[0] = make_float4(pt.x, pt.y, pt.z, depth);
+		return true;
+	}
+	return false;
+}
+// capsule vs capsule (:523-612) and capsule vs cylinder (:614-703): identical except for what the end-cap / general cases test against
+template <bool B_IS_CYLINDER>
+MI_DEV bool capsuleTube(Capsule a, Capsule b, Man& m)
 {
 	V3 aDir = a.b - a.a;
 	V3 bDir = normalize(b.b - b.a);
@@ -169,6 +201,7 @@ MI_DEV bool capsuleCapsule(Capsule a, Capsule b, Man& m) // :523-612
 		{
 			Sphere sa, sb; sa.r = a.r; sb.r = b.r;
 			if (a0 > b1) { sa.c = pAa; sb.c = pBb; } else { sa.c = pAb; sb.c = pBa; }
+			if (B_IS_CYLINDER) return sphereCylinder(sa, b, m);
 			return sphereSphere(sa, sb, m);
 		}
 		V3 contactA0 = ref + left * aDir, contactA1 = ref + right * aDir;
@@ -188,7 +221,52 @@ MI_DEV bool capsuleCapsule(Capsule a, Capsule b, Man& m) // :523-612
 	V3 c1, c2;
 	closestSegmentSegment(a.a, a.b, b.a, b.b, c1, c2);
 	Sphere sa, sb; sa.c = c1; sa.r = a.r; sb.c = c2; sb.r = b.r;
+	if (B_IS_CYLINDER) return sphereCylinder(sa, b, m);
 	return sphereSphere(sa, sb, m);
+}
+MI_DEV bool capsuleCapsule(Capsule a, Capsule b, Man& m) { return capsuleTube<false>(a, b, m); }
+MI_DEV bool capsuleCylinder(Capsule a, Capsule b, Man& m) { return capsuleTube<true>(a, b, m); }
+// cylinder vs cylinder, parallel branch (:821-903).  Returns 0 = no collision, 1 = manifold written, 2 = not parallel (GJK + EPA).
+MI_DEV int cylinderCylinderParallel(Capsule a, Capsule b, Man& m)
+{
+	V3 aDir = a.b - a.a;
+	V3 bDir = normalize(b.b - b.a);
+	float aDirLength = length(aDir);
+	aDir *= 1.f / aDirLength;
+	float parallel = dot(aDir, bDir);
+	if (!(fabsf(parallel) > 0.99f)) return 2;
+	V3 pBa = b.a, pBb = b.b;
+	if (parallel < 0.f) { V3 t = pBa; pBa = pBb; pBb = t; }
+	V3 ref = a.a;
+	float a0 = 0.f, a1 = aDirLength;
+	float b0 = dot(aDir, pBa - ref), b1 = dot(aDir, pBb - ref);
+	float left = fmaxf(a0, b0), right = fminf(a1, b1);
+	if (right < left) return 0;
+	V3 contactA0 = ref + left * aDir, contactA1 = ref + right * aDir;
+	V3 contactB0 = closestPointSegment(contactA0, pBa, pBb);
+	V3 contactB1 = contactB0 + (right - left) * aDir;
+	V3 normal = contactB0 - contactA0;
+	float d = length(normal);
+	float penetration = (a.r + b.r) - d;
+	if (penetration < 0.f) return 0;
+	float capPenetration = right - left;
+	if (capPenetration < penetration)
+	{
+		m.count = 1;
+		V3 pt;
+		if (b0 > a0) { m.n = aDir; pt = a.b - v3s(capPenetration * 0.5f); }   // vec3 - float broadcast, as :891/:897 do
+		else { m.n = -aDir; pt = a.a + v3s(capPenetration * 0.5f); }
+		m.p[0] = make_float4(pt.x, pt.y, pt.z, capPenetration);
+	}
+	else
+	{
+		if (d < MI_EPSILON) { d = 0.f; normal = v3(0.f, 1.f, 0.f); } else { normal = normal / d; }
+		m.n = normal; m.count = 2;
+		V3 p0 = (contactA0 + contactB0) * 0.5f, p1 = (contactA1 + contactB1) * 0.5f;
+		m.p[0] = make_float4(p0.x, p0.y, p0.z, penetration);
+		m.p[1] = make_float4(p1.x, p1.y, p1.z, penetration);
+	}
+	return 1;
 }
 MI_DEV bool boxBoxAxisAligned(Box a, Box b, Man& m) // :1074-1140
 {
@@ -477,10 +555,10 @@ MI_DEV bool obbObb(const Obb& a, const Obb& b, Man& m)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// GJK + EPA for capsule vs axis-aligned box — collision_gjk.h:17-28,48-61,140-238; collision_gjk.cpp:6-212;
-// collision_epa.h:96-168; collision_epa.cpp:5-239.  Array sizes: the reference's 1024-entry arrays can hold at most
-// 24 points after its 20 iterations; triangles/edges are sized from measured high-water marks (46 / 48 on the test scenes)
-// with 2x headroom, and the reference's out-of-memory exits are kept.
+// GJK + EPA for a tube (capsule / cylinder) vs an axis-aligned box or a cylinder — collision_gjk.h:17-61,140-238;
+// collision_gjk.cpp:6-212; collision_epa.h:96-168; collision_epa.cpp:5-239.  Array sizes: the reference's 1024-entry arrays can
+// hold at most 24 points after its 20 iterations; triangles/edges are sized above the measured high-water marks (98 / 100 over
+// all test scenes, same caps in oracle/onarrow.h), and the reference's out-of-memory exits are kept.
 // ---------------------------------------------------------------------------------------------------------------
 #define EPA_MAX_POINTS 24
 #define EPA_MAX_TRIANGLES 128
@@ -497,10 +575,24 @@ MI_DEV V3 capsuleSupport(const Capsule& c, V3 dir)
 	V3 farther = distA > distB ? c.a : c.b;
 	return normalize(dir) * c.r + farther;
 }
-MI_DEV V3 boxSupport(const Box& b, V3 dir) { return v3((dir.x < 0.f) ? b.lo.x : b.hi.x, (dir.y < 0.f) ? b.lo.y : b.hi.y, (dir.z < 0.f) ? b.lo.z : b.hi.z); }
-MI_DEV SupportPoint supportCB(const Capsule& c, const Box& b, V3 dir)
+MI_DEV V3 cylinderSupport(const Capsule& c, V3 dir) // collision_gjk.h:30-46
 {
-	SupportPoint s; s.a = capsuleSupport(c, dir); s.b = boxSupport(b, -dir); s.mk = s.a - s.b; return s;
+	float distA = dot(dir, c.a), distB = dot(dir, c.b);
+	V3 farther = distA > distB ? c.a : c.b;
+	V3 n = c.a - c.b;
+	V3 projectedDir = noz(cross(cross(n, dir), n));
+	return farther + projectedDir * c.r;
+}
+MI_DEV V3 boxSupport(const Box& b, V3 dir) { return v3((dir.x < 0.f) ? b.lo.x : b.hi.x, (dir.y < 0.f) ? b.lo.y : b.hi.y, (dir.z < 0.f) ? b.lo.z : b.hi.z); }
+// The two convex shapes of one GJK/EPA instance: A is a tube (capsule or cylinder), B an axis-aligned box or a cylinder.
+struct SupShapes { Capsule tubeA, tubeB; Box box; bool aIsCylinder, bIsCylinder; };
+MI_DEV SupportPoint supportPair(const SupShapes& sh, V3 dir)
+{
+	SupportPoint s;
+	s.a = sh.aIsCylinder ? cylinderSupport(sh.tubeA, dir) : capsuleSupport(sh.tubeA, dir);
+	s.b = sh.bIsCylinder ? cylinderSupport(sh.tubeB, -dir) : boxSupport(sh.box, -dir);
+	s.mk = s.a - s.b;
+	return s;
 }
 MI_DEV V3 crossABA(V3 a, V3 b) { return cross(cross(a, b), a); }
 
@@ -561,20 +653,20 @@ MI_DEV int updateGJKSimplex(GjkSimplex& s, const SupportPoint& a, V3& dir)
 	return 2;
 }
 
-MI_DEV bool gjkCapsuleBox(const Capsule& c, const Box& b, GjkSimplex& sx)
+MI_DEV bool gjkPair(const SupShapes& sh, GjkSimplex& sx)
 {
 	V3 dir = v3(1.f, 0.1f, -0.2f);
-	sx.c = supportCB(c, b, dir);
+	sx.c = supportPair(sh, dir);
 	if (dot(sx.c.mk, dir) < 0.f) return false;
 	dir = -sx.c.mk;
-	sx.b = supportCB(c, b, dir);
+	sx.b = supportPair(sh, dir);
 	if (dot(sx.b.mk, dir) < 0.f) return false;
 	dir = crossABA(sx.c.mk - sx.b.mk, -sx.b.mk);
 	sx.numPoints = 2;
 	for (u32 it = 0; it < GJK_MAX_ITERATIONS; ++it)
 	{
 		if (sqlen(dir) < 0.0001f) return false;
-		SupportPoint a = supportCB(c, b, dir);
+		SupportPoint a = supportPair(sh, dir);
 		if (dot(a.mk, dir) < 0.f) return false;
 		int res = updateGJKSimplex(sx, a, dir);
 		if (res == 0) { sx.a = a; sx.numPoints = 4; return true; }
@@ -583,140 +675,6 @@ MI_DEV bool gjkCapsuleBox(const Capsule& c, const Box& b, GjkSimplex& sx)
 	return false;
 }
 
-#if 0 // thread-per-pair EPA with private scratch: 3.2 ms at config 3 (3.7 KB of scratch per lane, every access a dependent HBM
-      // round trip).  Kept for reference only; the wave-cooperative LDS version below replaces it.
-struct EpaTri { u8 a, b, c, eA, eB, eC; u8 active, pad; V3 normal; float dist; };
-struct EpaEdge { u8 a, b, tA, tB; };
-struct Epa
-{
-	SupportPoint points[EPA_MAX_POINTS];
-	EpaTri tris[EPA_MAX_TRIANGLES];
-	EpaEdge edges[EPA_MAX_EDGES];
-	u32 numTris, numPoints, numEdges;
-};
-#define EPA_NONE 0xFFu
-
-MI_DEV void epaTriInfo(const SupportPoint& a, const SupportPoint& b, const SupportPoint& c, V3& normal, float& dist)
-{
-	normal = normalize(cross(b.mk - a.mk, c.mk - a.mk));
-	dist = dot(normal, a.mk);
-}
-MI_DEV u32 epaPushTri(Epa& e, u32 a, u32 b, u32 c, u32 eA, u32 eB, u32 eC, V3 normal, float dist)
-{
-	if (e.numTris >= EPA_MAX_TRIANGLES) return EPA_NONE;
-	u32 i = e.numTris++;
-	EpaTri& t = e.tris[i];
-	t.a = (u8)a; t.b = (u8)b; t.c = (u8)c; t.eA = (u8)eA; t.eB = (u8)eB; t.eC = (u8)eC; t.active = 1; t.normal = normal; t.dist = dist;
-	return i;
-}
-MI_DEV u32 epaPushEdge(Epa& e, u32 a, u32 b, u32 tA, u32 tB)
-{
-	if (e.numEdges >= EPA_MAX_EDGES) return EPA_NONE;
-	u32 i = e.numEdges++;
-	EpaEdge& ed = e.edges[i]; ed.a = (u8)a; ed.b = (u8)b; ed.tA = (u8)tA; ed.tB = (u8)tB;
-	return i;
-}
-MI_DEV bool epaAddPoint(Epa& e, const SupportPoint& np) // collision_epa.cpp:111-239
-{
-	u8 refs[EPA_MAX_EDGES];
-	for (u32 i = 0; i < e.numEdges; ++i) refs[i] = 0;
-	for (u32 i = 0; i < e.numTris; ++i)
-	{
-		EpaTri& t = e.tris[i];
-		if (t.active)
-		{
-			float d = dot(t.normal, np.mk - e.points[t.a].mk);
-			if (d > 0.f) { ++refs[t.eA]; ++refs[t.eB]; ++refs[t.eC]; t.active = 0; }
-		}
-	}
-	u8 border[EPA_MAX_BORDER];
-	u32 nBorder = 0;
-	for (u32 i = 0; i < e.numEdges; ++i)
-	{
-		if (refs[i] == 1) { if (nBorder >= EPA_MAX_BORDER) return false; border[nBorder++] = (u8)i; }
-	}
-	u8 newEdgePerPoint[EPA_MAX_POINTS];
-	if (e.numPoints >= EPA_MAX_POINTS) return false;
-	u32 newPoint = e.numPoints++;
-	e.points[newPoint] = np;
-	u32 triOffset = e.numTris;
-	for (u32 i = 0; i < nBorder; ++i)
-	{
-		u32 ei = border[i];
-		EpaEdge& edge = e.edges[ei];
-		bool triAActive = e.tris[edge.tA].active != 0;
-		bool triBActive = e.tris[edge.tB].active != 0;
-		u32 pointToConnect = triBActive ? edge.a : edge.b;
-		u32 triIndex = e.numTris;
-		u32 newEdge = epaPushEdge(e, pointToConnect, newPoint, EPA_NONE, e.numTris);
-		if (newEdge == EPA_NONE) return false;
-		newEdgePerPoint[pointToConnect] = (u8)newEdge;
-		u32 bi = pointToConnect, ci = triBActive ? edge.b : edge.a;
-		V3 n; float dist;
-		epaTriInfo(np, e.points[bi], e.points[ci], n, dist);
-		if (epaPushTri(e, newPoint, bi, ci, ei, EPA_NONE, newEdge, n, dist) == EPA_NONE) return false;
-		if (triAActive) edge.tB = (u8)triIndex; else edge.tA = (u8)triIndex;
-	}
-	for (u32 i = 0; i < nBorder; ++i)
-	{
-		EpaEdge& edge = e.edges[border[i]];
-		bool triBNew = edge.tB >= triOffset && edge.tB != EPA_NONE;
-		u32 pointToConnect = triBNew ? edge.a : edge.b;
-		u32 other = newEdgePerPoint[pointToConnect];
-		u32 triIndex = i + triOffset;
-		e.tris[triIndex].eB = (u8)other;
-		e.edges[other].tA = (u8)triIndex;
-	}
-	return true;
-}
-MI_DEV V3 barycentric(V3 a, V3 b, V3 c, V3 p) // math.cpp:1390-1408
-{
-	V3 v0 = b - a, v1 = c - a, v2 = p - a;
-	float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
-	float denom = d00 * d11 - d01 * d01;
-	denom = (fabsf(denom) < MI_EPSILON) ? 1.f : denom;
-	float v = (d11 * d20 - d01 * d21) / denom;
-	float w = (d00 * d21 - d01 * d20) / denom;
-	float u = 1.0f - v - w;
-	return v3(u, v, w);
-}
-MI_DEV void epaCapsuleBox(const GjkSimplex& g, const Capsule& c, const Box& b, V3& outPoint, V3& outNormal, float& outDepth)
-{
-	Epa e;
-	e.numTris = 0; e.numPoints = 4; e.numEdges = 0;
-	e.points[0] = g.a; e.points[1] = g.b; e.points[2] = g.c; e.points[3] = g.d;
-	V3 n; float d;
-	epaTriInfo(g.a, g.b, g.d, n, d); epaPushTri(e, 0, 1, 3, 4, 3, 0, n, d);
-	epaTriInfo(g.b, g.c, g.d, n, d); epaPushTri(e, 1, 2, 3, 5, 4, 1, n, d);
-	epaTriInfo(g.c, g.a, g.d, n, d); epaPushTri(e, 2, 0, 3, 3, 5, 2, n, d);
-	epaTriInfo(g.a, g.c, g.b, n, d); epaPushTri(e, 0, 2, 1, 1, 0, 2, n, d);
-	epaPushEdge(e, 0, 1, 0, 3); epaPushEdge(e, 1, 2, 1, 3); epaPushEdge(e, 2, 0, 2, 3);
-	epaPushEdge(e, 0, 3, 2, 0); epaPushEdge(e, 1, 3, 0, 1); epaPushEdge(e, 2, 3, 1, 2);
-	u32 closest = 0;
-	for (u32 it = 0; it < 20; ++it)
-	{
-		closest = 0xFFFFFFFFu;
-		float minD = MI_FLT_MAX;
-		for (u32 i = 0; i < e.numTris; ++i) { if (e.tris[i].active && e.tris[i].dist < minD) { minD = e.tris[i].dist; closest = i; } }
-		if (closest == 0xFFFFFFFFu) { closest = 0; break; }
-		EpaTri& tri = e.tris[closest];
-		SupportPoint a = supportCB(c, b, tri.normal);
-		float dd = dot(a.mk, tri.normal);
-		if (dd - tri.dist < 0.01f) break;
-		if (!epaAddPoint(e, a)) break;
-	}
-	EpaTri& tri = e.tris[closest];
-	const SupportPoint& pa = e.points[tri.a];
-	const SupportPoint& pb = e.points[tri.b];
-	const SupportPoint& pc = e.points[tri.c];
-	V3 bary = barycentric(pa.mk, pb.mk, pc.mk, tri.normal * tri.dist);
-	V3 pointA = bary.x * pa.a + bary.y * pb.a + bary.z * pc.a;
-	V3 pointB = bary.x * pa.b + bary.y * pb.b + bary.z * pc.b;
-	outPoint = 0.5f * (pointA + pointB);
-	outNormal = tri.normal;
-	outDepth = tri.dist;
-}
-#endif
 
 MI_DEV V3 barycentric(V3 a, V3 b, V3 c, V3 p) // math.cpp:1390-1408
 {
@@ -762,7 +720,7 @@ __device__ __forceinline__ void epaSetTri(EpaWave& e, u32 t, u32 a, u32 b, u32 c
 }
 
 // Runs on a full wave; every lane returns the same (point, normal, depth).
-__device__ void epaWaveCapsuleBox(EpaWave& e, u32 lane, const GjkSimplex& g, const Capsule& c, const Box& b, V3& outPoint, V3& outNormal, float& outDepth)
+__device__ void epaWave(EpaWave& e, u32 lane, const GjkSimplex& g, const SupShapes& sh, V3& outPoint, V3& outNormal, float& outDepth)
 {
 	u32 numTris = 4, numPoints = 4, numEdges = 6;
 	if (lane == 0)
@@ -791,7 +749,7 @@ __device__ void epaWaveCapsuleBox(EpaWave& e, u32 lane, const GjkSimplex& g, con
 		closest = bi;
 		if (closest == 0xFFFFFFFFu) { closest = 0; break; }
 		V3 tn = v3(e.tnx[closest], e.tny[closest], e.tnz[closest]);
-		SupportPoint np = supportCB(c, b, tn);
+		SupportPoint np = supportPair(sh, tn);
 		float dd = dot(np.mk, tn);
 		if (dd - e.tdist[closest] < 0.01f) break;
 
@@ -890,15 +848,20 @@ MI_DEV void capsuleBoxFinish(V3 point, V3 normal, float depth, const Capsule& c,
 		}
 	}
 }
-// intersection(capsule, obb) works in the box's frame (:771-790): operands for the shared capsule-vs-aabb code.
-MI_DEV void capsuleBoxOperands(u32 key, const ColliderRec& A, const ColliderRec& B, Capsule& c, Box& box, Obb& o)
+// Operands of one GJK/EPA instance by bucket key: 9 capsule-aabb, 10 capsule-obb, 14 cylinder-cylinder, 15 cylinder-aabb,
+// 16 cylinder-obb.  The obb variants work in the box's frame (:771-790, :1024-1043).
+MI_DEV void gjkOperands(u32 key, const ColliderRec& A, const ColliderRec& B, SupShapes& sh, Obb& o)
 {
-	c = asCapsule(A);
-	if (key == 9) { box = asBox(B); return; }
+	sh.tubeA = asCapsule(A);
+	sh.aIsCylinder = key >= 14;
+	sh.bIsCylinder = key == 14;
+	sh.tubeB = sh.tubeA; sh.box.lo = v3s(0.f); sh.box.hi = v3s(0.f);
+	if (key == 14) { sh.tubeB = asCapsule(B); return; }
+	if (key == 9 || key == 15) { sh.box = asBox(B); return; }
 	o = asObb(B);
-	box.lo = o.c - o.r; box.hi = o.c + o.r;
-	Capsule c_; c_.a = conjugate(o.q) * (c.a - o.c) + o.c; c_.b = conjugate(o.q) * (c.b - o.c) + o.c; c_.r = c.r;
-	c = c_;
+	sh.box.lo = o.c - o.r; sh.box.hi = o.c + o.r;
+	Capsule c_; c_.a = conjugate(o.q) * (sh.tubeA.a - o.c) + o.c; c_.b = conjugate(o.q) * (sh.tubeA.b - o.c) + o.c; c_.r = sh.tubeA.r;
+	sh.tubeA = c_;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -930,7 +893,7 @@ __global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(con
 	if (slot >= counters[CTR_NUM_VALID]) return;
 	u32 key = keySorted[slot];
 	bool mine;
-	if (GROUP == GROUP_CLOSED) mine = (key == 0 || key == 1 || key == 3 || key == 4 || key == 7 || key == 21);
+	if (GROUP == GROUP_CLOSED) mine = (key == 0 || key == 1 || key == 2 || key == 3 || key == 4 || key == 7 || key == 8 || key == 21);
 	else mine = (key == 22 || key == 28);
 	if (!mine) return;
 	u64 packed = pairSorted[slot];
@@ -944,9 +907,11 @@ __global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(con
 		{
 			case 0: hit = sphereSphere(asSphere(A), asSphere(B), m); break;
 			case 1: hit = sphereCapsule(asSphere(A), asCapsule(B), m); break;
+			case 2: hit = sphereCylinder(asSphere(A), asCapsule(B), m); break;
 			case 3: hit = sphereBox(asSphere(A), asBox(B), m); break;
 			case 4: hit = sphereObb(asSphere(A), asObb(B), m); break;
 			case 7: hit = capsuleCapsule(asCapsule(A), asCapsule(B), m); break;
+			case 8: hit = capsuleCylinder(asCapsule(A), asCapsule(B), m); break;
 			case 21: hit = boxBoxAxisAligned(asBox(A), asBox(B), m); break;
 		}
 	}
@@ -960,21 +925,28 @@ __global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(con
 	writeManifold(manifolds, slot, m, hit, A, B, slot);
 }
 
-// Capsule vs box, phase 1: the GJK boolean test over the contiguous slot range of keys 9..10 (registers only).  Misses write
+// Tube vs box / cylinder vs cylinder, phase 1: the GJK boolean test over the contiguous slot range of keys 9..16 (9, 10, 14, 15, 16
+// occur; 11 is a hull pair, 12 and 13 cannot occur with typeA <= typeB).  Parallel cylinder pairs finish here in closed form.  Misses write
 // their empty manifold; hits append (slot, simplex) to the EPA work list so that phase 2 runs with dense waves — the
 // expanding polytope needs ~3.7 KB of private scratch per lane and 20 serial iterations, which must not idle behind misses.
 __global__ void __launch_bounds__(256) k_gjk(u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
 	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, u32* __restrict__ epaList, float4* __restrict__ gjkSimplex)
 {
 	u32 slot = counters[CTR_BUCKET_START + 9] + blockIdx.x * blockDim.x + threadIdx.x;
-	if (slot >= counters[CTR_BUCKET_START + 11]) return;
+	if (slot >= counters[CTR_BUCKET_START + 17]) return;
 	u32 key = keySorted[slot];
 	u64 packed = pairSorted[slot];
 	ColliderRec A = colWorld[(u32)packed], B = colWorld[(u32)(packed >> 32)];
-	Capsule c; Box box; Obb o;
-	capsuleBoxOperands(key, A, B, c, box, o);
+	SupShapes sh; Obb o;
+	gjkOperands(key, A, B, sh, o);
+	if (key == 14)
+	{
+		Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
+		int r = cylinderCylinderParallel(sh.tubeA, sh.tubeB, m);
+		if (r != 2) { writeManifold(manifolds, slot, m, r == 1, A, B, slot); return; }
+	}
 	GjkSimplex sx;
-	if (!gjkCapsuleBox(c, box, sx))
+	if (!gjkPair(sh, sx))
 	{
 		Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
 		writeManifold(manifolds, slot, m, false, A, B, slot);
@@ -1006,8 +978,8 @@ __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) k_epa(const u32* __r
 		u32 key = keySorted[slot];
 		u64 packed = pairSorted[slot];
 		ColliderRec A = colWorld[(u32)packed], B = colWorld[(u32)(packed >> 32)];
-		Capsule c; Box box; Obb o;
-		capsuleBoxOperands(key, A, B, c, box, o);
+		SupShapes sh; Obb o;
+		gjkOperands(key, A, B, sh, o);
 		const float4* S = gjkSimplex + (size_t)j * 9;
 		float f[36];
 		for (u32 i = 0; i < 9; ++i) { float4 v = S[i]; f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w; }
@@ -1015,12 +987,13 @@ __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) k_epa(const u32* __r
 		SupportPoint* P[4] = { &sx.a, &sx.b, &sx.c, &sx.d };
 		for (u32 i = 0; i < 4; ++i) { P[i]->a = v3(f[9 * i], f[9 * i + 1], f[9 * i + 2]); P[i]->b = v3(f[9 * i + 3], f[9 * i + 4], f[9 * i + 5]); P[i]->mk = v3(f[9 * i + 6], f[9 * i + 7], f[9 * i + 8]); }
 		V3 point, normal; float depth;
-		epaWaveCapsuleBox(e, lane, sx, c, box, point, normal, depth);
+		epaWave(e, lane, sx, sh, point, normal, depth);
 		if (lane == 0)
 		{
 			Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
-			capsuleBoxFinish(point, normal, depth, c, box, m);
-			if (key == 10) // back to world space (:779-787)
+			if (key == 14) { m.n = normal; m.count = 1; m.p[0] = make_float4(point.x, point.y, point.z, depth); } // :905-950
+			else capsuleBoxFinish(point, normal, depth, sh.tubeA, sh.box, m);
+			if (key == 10 || key == 16) // back to world space (:779-787, :1032-1040)
 			{
 				m.n = o.q * m.n;
 				for (u32 i = 0; i < m.count; ++i)

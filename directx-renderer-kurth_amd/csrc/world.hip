@@ -135,6 +135,24 @@ static MassProps colliderMassProps(const World::HCollider& c)
 			I.m22 += temp2 * 2.f;
 			r.inertia = mtranspose(rot) * I * rot;
 		} break;
+		case MI_CYLINDER: // physics.cpp:1466-1494
+		{
+			V3 pA = v3(s[0], s[1], s[2]), pB = v3(s[3], s[4], s[5]); float radius = s[6];
+			V3 axis = pA - pB;
+			if (axis.y < 0.f) axis *= -1.f;
+			float height = length(axis);
+			axis *= (1.f / height);
+			M3 rot = quaternionToMat3(rotateFromTo(v3(0.f, 1.f, 0.f), axis));
+			float sqRadiusPI = MI_PI * radius * radius;
+			r.mass = (sqRadiusPI * length(pA - pB)) * c.density;
+			r.cog = (pA + pB) * 0.5f;
+			float sqRadius = radius * radius;
+			float sqHeight = height * height;
+			M3 I = mzero();
+			I.m11 = sqRadius * r.mass * 0.5f;
+			I.m00 = I.m22 = 1.f / 12.f * r.mass * (3.f * sqRadius + sqHeight);
+			r.inertia = mtranspose(rot) * I * rot;
+		} break;
 		case MI_AABB:
 		{
 			V3 lo = v3(s[0], s[1], s[2]), hi = v3(s[3], s[4], s[5]);
@@ -545,10 +563,10 @@ uint32_t mi_add_body(mi_world* world, int kinematic, float gravityFactor, float 
 
 static uint32_t addCollider(World* w, uint32_t body, uint32_t type, const float* shape, const mi_material* material, const float* pos, const float* rot)
 {
-	if (type != MI_SPHERE && type != MI_CAPSULE && type != MI_AABB && type != MI_OBB) { w->fail(MI_ERR_UNSUPPORTED, "collider type not supported by the HIP narrowphase (cylinder/hull)"); return 0xFFFFFFFFu; }
+	if (type > MI_OBB) { w->fail(MI_ERR_UNSUPPORTED, "collider type not supported by the HIP narrowphase (hull)"); return 0xFFFFFFFFu; }
 	if (body != MI_STATIC_BODY && body >= w->bodies.size()) { w->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_collider: body out of range"); return 0xFFFFFFFFu; }
 	World::HCollider c; memset(&c, 0, sizeof(c));
-	u32 n = (type == MI_SPHERE) ? 4 : (type == MI_CAPSULE ? 7 : (type == MI_AABB ? 6 : 10));
+	u32 n = (type == MI_SPHERE) ? 4 : ((type == MI_CAPSULE || type == MI_CYLINDER) ? 7 : (type == MI_AABB ? 6 : 10));
 	memcpy(c.shape, shape, n * sizeof(float));
 	c.restitution = material->restitution; c.friction = material->friction; c.density = material->density;
 	c.type = type; c.body = body;

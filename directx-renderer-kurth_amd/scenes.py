@@ -152,6 +152,40 @@ def c3_mixed(n=100000, seed=14878213, area=200.0, column_height=50, pitch=1.4, l
     return s
 
 
+def all_shapes(n=600, seed=90210377, column_height=6, pitch=1.6, layer=1.5):
+    """Every in-scope collider type (sphere, capsule, cylinder, AABB, OBB) in one pile: exercises all 15 type pairs incl. the
+    cylinder kernels (collision_narrow.cpp:408-449, 614-703, 821-1043).  Every fourth body starts axis-aligned so that the parallel
+    branches (abs(cos) > 0.99) and the face-clipping of tubes lying on the ground are hit."""
+    rng = XorShift64(seed)
+    s = Scene("all_shapes_%d" % n)
+    _ground(s, 30.0)
+    ncol = (n + column_height - 1) // column_height
+    side = int(math.ceil(math.sqrt(ncol)))
+    for i in range(n):
+        c, k = divmod(i, column_height)
+        cx = (c % side - 0.5 * (side - 1)) * pitch
+        cz = (c // side - 0.5 * (side - 1)) * pitch
+        pos = (cx + rng.between(-0.1, 0.1), 1.0 + layer * k + rng.between(0, 0.05), cz + rng.between(-0.1, 0.1))
+        rot = rng.unit_quat()
+        if i % 4 == 0:
+            rot = (0.0, 0.0, 0.0, 1.0)
+        b = s.add_body(pos, rot)
+        kind = i % 5
+        if kind == 0:
+            s.add_collider(b, SPHERE, (0, 0, 0, rng.between(0.3, 0.6)), DEFAULT_MATERIAL)
+        elif kind == 1:
+            s.add_collider(b, CAPSULE, (-0.5, 0, 0, 0.5, 0, 0, 0.25), DEFAULT_MATERIAL)
+        elif kind == 2:
+            s.add_collider(b, CYLINDER, (-0.5, 0, 0, 0.5, 0, 0, rng.between(0.25, 0.5)), DEFAULT_MATERIAL)
+        elif kind == 3:
+            he = (rng.between(0.3, 0.7), rng.between(0.3, 0.7), rng.between(0.3, 0.7))
+            s.add_collider(b, AABB, (-he[0], -he[1], -he[2]) + he, DEFAULT_MATERIAL)
+        else:
+            he = (rng.between(0.3, 0.8), rng.between(0.3, 0.8), rng.between(0.3, 0.8))
+            s.add_collider(b, OBB, (0, 0, 0, 1, 0, 0, 0) + he, DEFAULT_MATERIAL)
+    return s
+
+
 # ---- humanoid ragdoll (reference src/physics/ragdoll.cpp:10-123) ------------------------------------------
 def _quat_axis_angle(axis, angle):
     h = np.float32(angle) * np.float32(0.5)
@@ -282,4 +316,6 @@ def by_name(name):
         return c3_mixed(1000000, area=700.0)
     if name == "c3_mid":
         return c3_mixed(20000)
+    if name == "shapes":
+        return all_shapes()
     raise KeyError(name)

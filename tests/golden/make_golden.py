@@ -6,6 +6,7 @@ be built here — SURVEY.md §4/§8c — so these pin OUR restatement against re
 Fixtures (numpy .npz, loadable with allow_pickle=False):
   narrow_pairs.npz   10 in-scope collider type pairs x 48 seeded poses (incl. degenerate ones): scene description, world-space
                      colliders/AABBs, broadphase pair set and per-pair contacts as produced by one oracle step.
+  narrow_pairs_cylinder.npz  the same for the 5 type pairs that involve a cylinder.
   scheduler.npz      body-pair lists -> exact 8-lane slot tables of the greedy batch scheduler (constraints.cpp:51-184).
   c1_trajectory.npz  config 1 (64 OBBs on the ground): transforms + velocities after 1, 60, 120, 240 steps, scalar and 8-lane solver.
   ragdoll_trajectory.npz  one humanoid ragdoll dropped on the ground at 60 Hz (learned_locomotion.cpp:440-446,469-474): 1, 30, 120 steps.
@@ -24,7 +25,7 @@ sys.path.insert(0, ROOT)
 from directx_renderer_kurth_amd import scenes  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
-SPHERE, CAPSULE, AABB, OBB = 0, 1, 3, 4
+SPHERE, CAPSULE, CYLINDER, AABB, OBB = 0, 1, 2, 3, 4
 MAT = (0.1, 0.5, 1.0)
 
 
@@ -40,17 +41,17 @@ def scene_from_arrays(bodies, cols, name="fixture", dt=1.0 / 120.0):
     s = scenes.Scene(name, dt)
     for b in bodies:
         s.add_body(b[0:3], b[3:7], kinematic=bool(b[7]), gravity_factor=float(b[8]), linear_damping=float(b[9]), angular_damping=float(b[10]))
-    nshape = {0: 4, 1: 7, 3: 6, 4: 10}
+    nshape = {0: 4, 1: 7, 2: 7, 3: 6, 4: 10}
     for c in cols:
         ctype = int(c[1])
         s.add_collider(int(c[0]), ctype, [np.float32(x) for x in c[2:2 + nshape[ctype]]], tuple(np.float32(c[12:15])), tuple(np.float32(c[15:18])), tuple(np.float32(c[18:22])))
     return s
 
 
-def narrow_scene(seed=7321, per_pair=48):
+def narrow_scene(seed=7321, per_pair=48, kinds=("sphere", "capsule", "aabb", "obb"), only_with=None):
     rng = scenes.XorShift64(seed)
     s = scenes.Scene("narrow_pairs")
-    kinds = ["sphere", "capsule", "aabb", "obb"]
+    kinds = list(kinds)
     case = 0
 
     def shape(kind):
@@ -59,6 +60,9 @@ def narrow_scene(seed=7321, per_pair=48):
         if kind == "capsule":
             h = rng.between(0.3, 0.6)
             return CAPSULE, (0, -h, 0, 0, h, 0, rng.between(0.2, 0.4)), 1.0
+        if kind == "cylinder":
+            h = rng.between(0.3, 0.6)
+            return CYLINDER, (0, -h, 0, 0, h, 0, rng.between(0.2, 0.5)), 1.0
         he = (rng.between(0.3, 0.6), rng.between(0.3, 0.6), rng.between(0.3, 0.6))
         if kind == "aabb":
             return AABB, (-he[0], -he[1], -he[2], he[0], he[1], he[2]), 1.0
@@ -67,6 +71,8 @@ def narrow_scene(seed=7321, per_pair=48):
 
     for ia, ka in enumerate(kinds):
         for kb in kinds[ia:]:
+            if only_with is not None and only_with not in (ka, kb):
+                continue
             for k in range(per_pair):
                 base = ((case % 32) * 40.0, 5.0, (case // 32) * 40.0)
                 ta, sa, ra = shape(ka)
@@ -90,8 +96,8 @@ def narrow_scene(seed=7321, per_pair=48):
     return s
 
 
-def gen_narrow():
-    s = narrow_scene()
+def gen_narrow(fname="narrow_pairs.npz", **kw):
+    s = narrow_scene(**kw)
     w = s.instantiate(orc.OracleWorld())
     w.step_internal(1e-9, 1)
     cols, aabbs = w.world_colliders()
@@ -99,10 +105,10 @@ def gen_narrow():
     cpairs, counts = w.collisions()
     contacts, bp, ci = w.contacts()
     bodies, carr = scene_to_arrays(s)
-    np.savez_compressed(os.path.join(HERE, "narrow_pairs.npz"), bodies=bodies, colliders=carr, world_colliders=cols.view(np.uint8).reshape(len(cols), 64),
+    np.savez_compressed(os.path.join(HERE, fname), bodies=bodies, colliders=carr, world_colliders=cols.view(np.uint8).reshape(len(cols), 64),
                         aabbs=aabbs, pairs=pairs, colliding_pairs=cpairs, counts=counts, contacts=contacts.view(np.uint8).reshape(len(contacts), 32),
                         contact_collision=ci, mass=w.mass_properties())
-    print("narrow_pairs: %d bodies, %d pairs, %d collisions, %d contacts" % (len(bodies), len(pairs), len(cpairs), len(contacts)), orc.stats())
+    print(fname + ": %d bodies, %d pairs, %d collisions, %d contacts" % (len(bodies), len(pairs), len(cpairs), len(contacts)), orc.stats())
 
 
 def gen_scheduler():
@@ -165,6 +171,7 @@ def gen_kat():
 if __name__ == "__main__":
     orc.build()
     gen_narrow()
+    gen_narrow("narrow_pairs_cylinder.npz", seed=99173, per_pair=64, kinds=("sphere", "capsule", "cylinder", "aabb", "obb"), only_with="cylinder")
     gen_scheduler()
     gen_trajectory("c1_trajectory.npz", scenes.c1_boxes(), (1, 60, 120, 240), (("scalar", orc.SOLVER_SCALAR), ("wide8", orc.SOLVER_WIDE8)))
     ragdoll = scenes.c4_ragdolls(1)

