@@ -48,7 +48,7 @@ class WorldDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("numRigidBodies", C.c_uint32), ("numColliders", C.c_uint32), ("numBroadphaseOverlaps", C.c_uint32), ("numCollisions", C.c_uint32),
                 ("numContacts", C.c_uint32), ("numColors", C.c_uint32), ("numJoints", C.c_uint32), ("numInternalSteps", C.c_uint32),
-                ("numGraphBuilds", C.c_uint32), ("coloringRounds", C.c_uint32),
+                ("numGraphBuilds", C.c_uint32), ("coloringRounds", C.c_uint32), ("flowProbes", C.c_uint32),
                 ("msCollidersBroad", C.c_float), ("msNarrow", C.c_float), ("msSolverSetup", C.c_float), ("msSolve", C.c_float),
                 ("msIntegrate", C.c_float), ("msTotal", C.c_float)]
 
@@ -64,7 +64,7 @@ EXPORTED_SYMBOLS = [
     "mi_set_transform", "mi_write_transforms", "mi_write_velocities", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
     "mi_get_stats", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_debug_num_pairs", "mi_debug_read_pairs",
     "mi_debug_read_world_colliders", "mi_debug_num_manifold_slots", "mi_debug_read_manifolds", "mi_debug_num_colors", "mi_debug_read_schedule",
-    "mi_debug_read_joint_order", "mi_debug_read_body_state",
+    "mi_debug_read_joint_order", "mi_debug_read_body_state", "mi_debug_flow_trace",
 ]
 
 
@@ -288,6 +288,11 @@ class World:
         out = np.zeros(max(n, 1), np.uint32)
         self._check(self.lib.mi_debug_read_joint_order(self.w, ctype, _p(out)))
         return out[:n]
+
+    def flow_trace(self, enable=True, num_slots=0):
+        out = np.zeros((max(1, num_slots), 32), np.uint64)
+        self._check(self.lib.mi_debug_flow_trace(self.w, int(enable), _p(out) if num_slots else None, C.c_uint32(num_slots)))
+        return out
 
     def body_state(self):
         n = self.num_bodies + 1

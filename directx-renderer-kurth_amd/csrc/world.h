@@ -71,8 +71,15 @@ enum
 	CTR_NUM_CONTACTS = 10,  // sum of contact counts over the active manifolds
 	CTR_PAIR_OVERFLOW = 11, // some collider has more broadphase partners than its slab holds
 	CTR_FIRST_INACTIVE = 12,// sorted position of the first collider whose body is simulated by another GPU
+	CTR_FLOW_STATUS = 13,   // dataflow sweep: non-zero = a lane gave up waiting (result invalid); cleared by k_color_offsets
+	CTR_FLOW_PROBES = 14,   // dataflow sweep: number of record polls of the step (must directly follow CTR_FLOW_STATUS)
 	CTR_BUCKET_START = 16,  // 65 words: first slot of narrowphase bucket key b (tA*6+tB); [64] unused
 	CTR_KEY_START = 96,     // (MI_MAX_COLORS+1)*4 + 1 words: first schedule slot of key colour*4 + (4-count); last = numManifolds
+	CTR_FLOW_CENSUS = 368,  // 16 words: workgroups of the running dataflow launch per XCD [0..7], registered [8], finished [9]
+	CTR_REGION_START = 384, // 9 words: first position in flowOrder of XCD region r; [8] = numManifolds
+	CTR_REGION_CUTS = 400,  // 7 floats: region r holds bodies with cuts[r-1] <= x < cuts[r]
+	CTR_REGION_RANGE = 408, // 2 floats: [lo, hi] of the histogram that produces the next cuts
+	CTR_REGION_MINMAX = 410,// 2 words: running min / max of x (order-preserving integer encoding) for the next range
 	CTR_WORDS = 512,
 };
 #define MI_NUM_SCHEDULE_KEYS ((MI_MAX_COLORS + 1) * 4)
@@ -112,6 +119,14 @@ struct World
 	DevBuf<uint4> actIds;                 // active manifolds: (bodyA, bodyB, count, slot)
 	DevBuf<u32> epaList; DevBuf<float4> gjkSimplex; // GJK hits -> EPA work list (9 float4 per hit)
 	DevBuf<float4> rowPlanes, rowShared; DevBuf<float2> rowLambda; DevBuf<uint4> rowIds;
+	DevBuf<u64> flow;                     // dataflow sweep: 8 x u64 per body {fp32 value, turn}
+	DevBuf<u32> regMask, mRegion, mRegionSorted, flowOrder, regionHist; // XCD regions: per-body region set, per-slot region, region-major slot order
+	bool regionsReady = false, useFlowRegions = false; u32 flowRegions = 1; // XCD regions: MI_FLOW_REGIONS=1 (no measured gain yet)
+	u32 flowMaxManifolds = 0xFFFFFFFFu;   // the dataflow kernel takes the colours at the end of the schedule holding at most this many manifolds, launches the rest (MI_FLOW_MAX; default: everything)
+	DevBuf<u64> flowTrace;                // developer timeline (mi_debug_flow_trace): 32 x u64 per slot, allocated on request only
+	u32 flowEpoch = 0, flowMaxBlocks[2] = { 0, 0 };
+	bool useFlow = true;                  // MI_PHYSICS_NO_FLOW=1: launch-per-colour sweep only
+	u32 flowHopTicks = 100, flowBackoffCap = 64, flowPredictFrac = 192; // poll pacing: 10 ns ticks; fraction (/256) of the iteration period slept through (MI_FLOW_HOP / _CAP / _PREDICT)
 	DevBuf<uint8_t> tempStorage;
 	DevBuf<u32> dCounters; u32* hCounters = nullptr; // CTR_WORDS words each
 	size_t pairCap = 0, rowCap = 0;
@@ -155,6 +170,10 @@ void launch_integrate_forces(World& w, float dt);
 void launch_coloring(World& w, u32 numPairs);
 void launch_contact_init(World& w, u32 numPairs, float dt);
 void launch_solve_contacts_iteration(World& w, const u32* gridBlocks, u32 numColors, u32 firstTail, bool serialBucket);
+void launch_solve_flow(World& w, u32 numManifolds, u32 itBegin, u32 itEnd, u32 firstColor);
+void launch_flow_regions(World& w, u32 numManifolds);       // region-major slot order for the XCD-local dataflow sweep
+u32 flow_num_regions(const World& w);
+void flow_choose_regions(World& w);
 void launch_integrate_velocities(World& w, float dt);
 void launch_joint_init(World& w, float dt);
 void launch_joint_solve_iteration(World& w);

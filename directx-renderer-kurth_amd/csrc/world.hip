@@ -47,6 +47,12 @@ World::World(int dev) : device(dev)
 	stageEvents.resize(8);
 	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
 	useGraph = getenv("MI_PHYSICS_NO_GRAPH") == nullptr; // rocprofv3's kernel trace needs plain launches
+	useFlow = getenv("MI_PHYSICS_NO_FLOW") == nullptr;   // dataflow contact sweep (one launch) vs one launch per colour
+	useFlowRegions = getenv("MI_FLOW_REGIONS") != nullptr;
+	if (const char* e = getenv("MI_FLOW_MAX")) flowMaxManifolds = (u32)atoi(e);
+	if (const char* e = getenv("MI_FLOW_HOP")) flowHopTicks = (u32)atoi(e);
+	if (const char* e = getenv("MI_FLOW_CAP")) flowBackoffCap = (u32)atoi(e);
+	if (const char* e = getenv("MI_FLOW_PREDICT")) flowPredictFrac = (u32)atoi(e);
 }
 
 World::~World()
@@ -397,6 +403,35 @@ static void runSolverSweep(World& w, u32 iters, u32 numColors)
 	for (auto& js : w.joints) numJointKernels += js.colorStart.empty() ? 0 : (u32)js.colorStart.size() - 1;
 	if (!numColors && !serial && !numJointKernels) return;
 
+	if (w.useFlow && numColors && !serial)
+	{
+		// Hybrid sweep.  The colours at the end of the schedule that together hold at most flowMaxManifolds manifolds (the long, thin
+		// tail of the greedy colouring: most of the colours, few of the manifolds) run in the dataflow kernel, where a colour step
+		// costs a hand-over (~2 us) instead of a launch (~5 us); the big colours in front keep their launches (a lane per manifold
+		// polling for its turn does not scale to 100k+ lanes: the sweep then advances at the pace of the slowest lane of every wave).
+		// If the whole schedule fits and there are no joints, all iterations run in ONE launch; otherwise one dataflow launch per
+		// iteration (joints are solved before the contacts in every iteration, constraints.cpp:3748-3772).
+		u32 numManifolds = w.hCounters[CTR_NUM_MANIFOLDS];
+		u32 firstFlow = numColors;
+		while (firstFlow > 0 && numManifolds - keyStart[4 * (firstFlow - 1)] <= w.flowMaxManifolds) --firstFlow;
+		if (firstFlow + 1 >= numColors && firstFlow > 0) firstFlow = numColors; // a one-colour tail is just a launch
+		if (firstFlow < numColors)
+		{
+			if (firstFlow == 0 && !numJointKernels)
+			{
+				launch_flow_regions(w, numManifolds);
+				launch_solve_flow(w, numManifolds, 0, iters, 0);
+			}
+			else for (u32 it = 0; it < iters; ++it)
+			{
+				launch_joint_solve_iteration(w);
+				if (firstFlow) launch_solve_contacts_iteration(w, need, firstFlow, firstFlow, false);
+				launch_solve_flow(w, numManifolds, it, it + 1, firstFlow);
+			}
+			return;
+		}
+	}
+
 	World::SolveGraph& g = w.solveGraph;
 	if (!w.useGraph)
 	{
@@ -439,6 +474,13 @@ int World::stepInternal(float dt, u32 iters)
 	launch_build_colliders(*this);
 	launch_broadphase_count(*this);
 	readCounters(*this);                                   // sync #1: number of overlapping pairs
+	if (hCounters[CTR_FLOW_STATUS])                        // the previous step's dataflow sweep gave up waiting: its result is invalid
+	{
+		useFlow = false;
+		fail(MI_ERR_HIP, "dataflow contact sweep gave up waiting (status " + std::to_string(hCounters[CTR_FLOW_STATUS]) + ": 1 = hand-over, 2 = census, 4 = unserved XCD region; GPU shared with another persistent kernel?); set MI_PHYSICS_NO_FLOW=1");
+		return lastError;
+	}
+	stats.flowProbes = hCounters[CTR_FLOW_PROBES];
 	u32 numPairs = hCounters[CTR_NUM_PAIRS];
 	ensurePairBuffers(*this, numPairs);
 	launch_broadphase_write(*this, numPairs);
@@ -448,6 +490,7 @@ int World::stepInternal(float dt, u32 iters)
 	if (T) MI_CHECK(hipEventRecord(stageEvents[2], stream));
 
 	launch_integrate_forces(*this, dt);
+	flow_choose_regions(*this);
 	launch_coloring(*this, numPairs);
 	launch_contact_init(*this, numPairs, dt);
 	launch_joint_init(*this, dt);
@@ -970,6 +1013,16 @@ int mi_debug_read_body_state(mi_world* world, float* outCog4, float* outInvInert
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	n = std::min<u32>(n, W->nb + 1);
 	d2h(W, outCog4, W->cog.p, sizeof(float4) * n); d2h(W, outInvInertia12, W->invIw.p, sizeof(float4) * 3 * n);
+	return W->lastError;
+}
+/* Developer timeline of the dataflow sweep: enable (allocates 256 B per manifold slot), step, then read 32 wall-clock stamps
+ * (10 ns ticks) per schedule slot: when the slot's manifold finished iteration i. */
+int mi_debug_flow_trace(mi_world* world, int enable, unsigned long long* out, uint32_t numSlots)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (enable && W->flowTrace.cap < (size_t)W->pairCap * 32) { W->flowTrace.ensure((size_t)W->pairCap * 32, W->stream); MI_CHECK(hipMemsetAsync(W->flowTrace.p, 0, sizeof(u64) * W->pairCap * 32, W->stream)); }
+	if (out && W->flowTrace.p) d2h(W, out, W->flowTrace.p, sizeof(u64) * 32 * std::min<size_t>(numSlots, W->pairCap));
+	if (!enable) W->flowTrace.release();
 	return W->lastError;
 }
 

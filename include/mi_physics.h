@@ -62,6 +62,7 @@ typedef struct mi_stats
 	uint32_t numRigidBodies, numColliders, numBroadphaseOverlaps, numCollisions, numContacts;
 	uint32_t numColors, numJoints, numInternalSteps;
 	uint32_t numGraphBuilds, coloringRounds; /* solver-sweep hipGraph (re)builds so far; colouring round budget of the last step */
+	uint32_t flowProbes;                     /* dataflow contact sweep: body-record polls of the step before the last one (0 = launch sweep) */
 	float msCollidersBroad, msNarrow, msSolverSetup, msSolve, msIntegrate, msTotal; /* HIP-event times, only when timing is enabled */
 } mi_stats;
 
@@ -152,6 +153,9 @@ uint32_t mi_debug_num_colors(mi_world* w);
 int mi_debug_read_schedule(mi_world* w, uint32_t* outManifoldSlots, uint32_t* outColorStart /* numColors+1 */);
 int mi_debug_read_joint_order(mi_world* w, uint32_t type, uint32_t* outJointIds);
 int mi_debug_read_body_state(mi_world* w, float* outCog4, float* outInvInertia12, uint32_t nPlusOne); /* rbGlobal: {cog.xyz, invMass}, 3 x float4 columns */
+/* Developer timeline of the dataflow contact sweep: enable != 0 allocates it (32 x u64 per schedule slot), out (may be NULL) receives the
+ * wall-clock stamp (10 ns ticks) at which each slot's manifold finished iteration i of the last step. */
+int mi_debug_flow_trace(mi_world* w, int enable, unsigned long long* out, uint32_t numSlots);
 
 #ifdef __cplusplus
 }
