@@ -116,7 +116,8 @@ def main():
         mean = {k: v / K for k, v in acc.items()}
         ms_per_step = elapsed / K * 1e3
         contacts = mean["numContacts"]
-        launches_per_step = max(1.0, mean["numColors"]) * 30.0
+        flow = mean.get("flowProbes", 0.0) > 0.0  # dataflow sweep: all 30 iterations in ONE launch of k_solve_flow
+        launches_per_step = 1.0 if flow else max(1.0, mean["numColors"]) * 30.0
         bytes_per_step = ALGORITHMIC_BYTES_PER_CONTACT_ITERATION * contacts * 30.0
         solve_s = mean["msSolve"] * 1e-3
         achieved = bytes_per_step / solve_s / 1e9 if solve_s > 0 else 0.0
@@ -129,7 +130,7 @@ def main():
                        "contacts": round(contacts), "colors": round(mean["numColors"], 1), "joints": round(mean["numJoints"]),
                        "parallelism": "1 gpu" if world_size == 1 else "%d spatial slabs + ghost-body halo over RCCL" % world_size},
             "stage_ms": {k: round(mean[k], 4) for k in ("msCollidersBroad", "msNarrow", "msSolverSetup", "msSolve", "msIntegrate", "msTotal")},
-            "roofline": {"bound": "hbm", "kernel": "k_solve_color (contact PGS sweep)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "k_solve_flow (contact PGS sweep, 30 iterations, dataflow)" if flow else "k_solve_color (contact PGS sweep, one launch per colour and iteration)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_launch": bytes_per_step / launches_per_step, "avg_launch_us": solve_s / launches_per_step * 1e6,
                          "launches_per_step": launches_per_step},

@@ -494,18 +494,28 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 // Body record: 64 B (one line per body); half 0 = {v.xyz, turn} at +0, half 1 = {w.xyz, turn} at +16.  Each half is ONE 16-byte
 // sc1 (agent-scope, write-through) store and ONE 16-byte sc1 load, and carries its own turn tag, so no ordering between the halves
 // and no release/acquire fence is needed (MI355X_MICROARCH.md, inter-workgroup visibility: tagged granules).
-MI_DEV bool flowLoad(__amdgpu_buffer_rsrc_t rsrc, u32 body, u32 want, u32 rank, V3& v, V3& w, u32& behind)
+// A poll is issued for both bodies at once (all four 16-byte loads in flight together: one L2 round trip per polling trip) and
+// evaluated afterwards.
+struct FlowPoll { u32x4 h0, h1; };
+// `eager`: fetch both halves with every poll (lowest latency; small and mid worlds).  Otherwise only the tagged first half is polled
+// and the second one fetched after a match: half the L2 requests, which is what bounds the sweep beyond ~130k polling lanes.
+MI_DEV void flowPollIssue(FlowPoll& p, __amdgpu_buffer_rsrc_t rsrc, u32 body, bool eager)
 {
 	asm volatile("" ::: "memory"); // a poll must be re-issued every time
-	u32x4 h0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, body * 64u, 0, 16); // the poll: ONE 16-byte request (polling is L2-request bound)
-	u32 d = want - h0.w;
+	p.h0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, body * 64u, 0, 16);
+	if (eager) p.h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, body * 64u + 16u, 0, 16);
+}
+MI_DEV bool flowPollCheck(FlowPoll& p, __amdgpu_buffer_rsrc_t rsrc, u32 body, bool eager, u32 want, u32 rank, V3& v, V3& w, u32& behind)
+{
+	u32 d = want - p.h0.w;
 	behind = (d > 4096u) ? rank : d;  // a stale record from an earlier launch: nobody has used the body in this launch yet
 	behind = behind > 8u ? 8u : behind;
-	if (h0.w != want) return false;
-	u32x4 h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, body * 64u + 16u, 0, 16); // stored before half 0; re-polled if it is not there yet
-	v = v3(__uint_as_float(h0.x), __uint_as_float(h0.y), __uint_as_float(h0.z));
-	w = v3(__uint_as_float(h1.x), __uint_as_float(h1.y), __uint_as_float(h1.z));
-	return h1.w == want;
+	if (p.h0.w != want) return false;
+	if (!eager) p.h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, body * 64u + 16u, 0, 16); // stored before half 0; re-polled if not there yet
+	if (p.h1.w != want) return false;
+	v = v3(__uint_as_float(p.h0.x), __uint_as_float(p.h0.y), __uint_as_float(p.h0.z));
+	w = v3(__uint_as_float(p.h1.x), __uint_as_float(p.h1.y), __uint_as_float(p.h1.z));
+	return true;
 }
 // `local`: every user of the body runs on this XCD, so the record may stay in this XCD's L2 (plain store; the polls bypass L1 and hit
 // L2).  Otherwise write-through (sc1), the only store flavour another XCD's loads can observe.
@@ -556,7 +566,7 @@ MI_DEV void flowItemLoad(FlowItem& m, u32 s, u32 nb, size_t rowCap, const float4
 
 // One use of the manifold (iteration `it`): wait for both bodies, solve, hand both bodies on.  Returns the number of polls.
 MI_DEV u32 flowTrip(FlowItem& m, u32 it, u32 itBegin, u32 itEnd, u32 epoch, __amdgpu_buffer_rsrc_t rsrc, size_t rowCap, const float4* __restrict__ rowPlanes,
-	float2* __restrict__ rowLambda, float4* vel, u32* status, u32 hopTicks, u32 backoffCap, u64 notBefore, u64& readyAt)
+	float2* __restrict__ rowLambda, float4* vel, u32* status, u32 hopTicks, u32 backoffCap, u64 notBefore, u64& readyAt, bool eager)
 {
 	const u32 a = m.a, b = m.b;
 	u32 wantA = epoch + (it - itBegin) * m.degA + m.rankA, wantB = epoch + (it - itBegin) * m.degB + m.rankB;
@@ -574,10 +584,14 @@ MI_DEV u32 flowTrip(FlowItem& m, u32 it, u32 itBegin, u32 itEnd, u32 epoch, __am
 	{
 		u64 now = wall_clock64();
 		bool probed = false;
-		if (needA && now >= nextA)
+		bool pollA = needA && now >= nextA, pollB = needB && now >= nextB;
+		FlowPoll pa, pb;
+		if (pollA) flowPollIssue(pa, rsrc, a, eager);
+		if (pollB) flowPollIssue(pb, rsrc, b, eager);
+		if (pollA)
 		{
-			V3 v, w; u32 behind;
-			if (flowLoad(rsrc, a, wantA, m.rankA, v, w, behind)) { vA = v; wA = w; needA = false; }
+			u32 behind;
+			if (flowPollCheck(pa, rsrc, a, eager, wantA, m.rankA, vA, wA, behind)) needA = false;
 			else
 			{
 				backA = backA ? (backA * 2u > backoffCap ? backoffCap : backA * 2u) : 8u;
@@ -586,10 +600,10 @@ MI_DEV u32 flowTrip(FlowItem& m, u32 it, u32 itBegin, u32 itEnd, u32 epoch, __am
 			}
 			probed = true; ++probes;
 		}
-		if (needB && now >= nextB)
+		if (pollB)
 		{
-			V3 v, w; u32 behind;
-			if (flowLoad(rsrc, b, wantB, m.rankB, v, w, behind)) { vB = v; wB = w; needB = false; }
+			u32 behind;
+			if (flowPollCheck(pb, rsrc, b, eager, wantB, m.rankB, vB, wB, behind)) needB = false;
 			else
 			{
 				backB = backB ? (backB * 2u > backoffCap ? backoffCap : backB * 2u) : 8u;
@@ -645,8 +659,9 @@ template <int BLOCKS_PER_CU>
 __global__ void __launch_bounds__(256, BLOCKS_PER_CU) k_solve_flow(u32* counters, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes,
 	const float4* __restrict__ rowShared, float2* __restrict__ rowLambda, const uint4* __restrict__ rowIds, const u32* __restrict__ keySorted,
 	const u64* __restrict__ bodyMask, float4* vel, u64* flow, u32 flowBytes, u32 epoch, u32 itBegin, u32 itEnd, u32 hopTicks, u32 backoffCap, u32 predictFrac,
-	u32 numRegions, const u32* __restrict__ flowOrder, const u32* __restrict__ regMask, u64* __restrict__ trace, u32 firstColor)
+	u32 numRegions, const u32* __restrict__ flowOrder, const u32* __restrict__ regMask, u64* __restrict__ trace, u32 firstColor, u32 eagerPolls)
 {
+	const bool eager = eagerPolls != 0u;
 	u32* status = counters + CTR_FLOW_STATUS;
 	u32* census = counters + CTR_FLOW_CENSUS;
 	const u32 numM = counters[CTR_NUM_MANIFOLDS];
@@ -698,7 +713,7 @@ __global__ void __launch_bounds__(256, BLOCKS_PER_CU) k_solve_flow(u32* counters
 				for (u32 it = itBegin; it < itEnd; ++it)
 				{
 					u64 notBefore = (period && predictFrac) ? readyPrev + (((u64)period * predictFrac) >> 8) : 0ull;
-					probes += flowTrip(m, it, itBegin, itEnd, epoch, rsrc, rowCap, rowPlanes, rowLambda, vel, status, hopTicks, backoffCap, notBefore, readyNow);
+					probes += flowTrip(m, it, itBegin, itEnd, epoch, rsrc, rowCap, rowPlanes, rowLambda, vel, status, hopTicks, backoffCap, notBefore, readyNow, eager);
 					period = readyPrev ? (u32)(readyNow - readyPrev) : 0u;
 					readyPrev = readyNow;
 					if (trace) trace[(size_t)slot * 32 + (it & 31u)] = wall_clock64(); // developer timeline: when this manifold finished iteration it
@@ -715,7 +730,7 @@ __global__ void __launch_bounds__(256, BLOCKS_PER_CU) k_solve_flow(u32* counters
 					FlowItem m;
 					flowItemLoad(m, slot, nb, rowCap, rowPlanes, rowShared, rowLambda, rowIds, keySorted, bodyMask, vel, numRegions, regMask, colourMask);
 					u64 readyNow;
-					probes += flowTrip(m, it, itBegin, itEnd, epoch, rsrc, rowCap, rowPlanes, rowLambda, vel, status, hopTicks, backoffCap, 0ull, readyNow);
+					probes += flowTrip(m, it, itBegin, itEnd, epoch, rsrc, rowCap, rowPlanes, rowLambda, vel, status, hopTicks, backoffCap, 0ull, readyNow, eager);
 					rowLambda[slot] = m.r0.lam;
 				}
 		}
@@ -764,7 +779,7 @@ void launch_solve_flow(World& w, u32 numManifolds, u32 itBegin, u32 itEnd, u32 f
 	auto kernel = variant == 0 ? k_solve_flow<3> : k_solve_flow<2>;
 	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, w.stream, w.dCounters.p, w.nb, w.rowCap, w.rowPlanes.p, w.rowShared.p, w.rowLambda.p, w.rowIds.p,
 		w.mKeySorted.p, w.bodyMask.p, w.vel.p, w.flow.p, (u32)(words * sizeof(u64)), w.flowEpoch << 12, itBegin, itEnd, w.flowHopTicks, w.flowBackoffCap, w.flowPredictFrac,
-		regions, w.flowOrder.p, w.regMask.p, w.flowTrace.p, firstColor);
+		regions, w.flowOrder.p, w.regMask.p, w.flowTrace.p, firstColor, numManifolds <= w.flowEagerMax ? 1u : 0u);
 }
 
 // One Gauss-Seidel iteration over all contact colours; colour c < firstTail is launched with gridBlocks[c] blocks (0 = skip),

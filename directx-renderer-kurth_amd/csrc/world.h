@@ -122,6 +122,7 @@ struct World
 	DevBuf<u64> flow;                     // dataflow sweep: 8 x u64 per body {fp32 value, turn}
 	DevBuf<u32> regMask, mRegion, mRegionSorted, flowOrder, regionHist; // XCD regions: per-body region set, per-slot region, region-major slot order
 	bool regionsReady = false, useFlowRegions = false; u32 flowRegions = 1; // XCD regions: MI_FLOW_REGIONS=1 (no measured gain yet)
+	u32 flowEagerMax = 131072;            // up to this many manifolds every poll fetches both record halves (MI_FLOW_EAGER)
 	u32 flowMaxManifolds = 0xFFFFFFFFu;   // the dataflow kernel takes the colours at the end of the schedule holding at most this many manifolds, launches the rest (MI_FLOW_MAX; default: everything)
 	DevBuf<u64> flowTrace;                // developer timeline (mi_debug_flow_trace): 32 x u64 per slot, allocated on request only
 	u32 flowEpoch = 0, flowMaxBlocks[2] = { 0, 0 };

@@ -50,6 +50,7 @@ World::World(int dev) : device(dev)
 	useFlow = getenv("MI_PHYSICS_NO_FLOW") == nullptr;   // dataflow contact sweep (one launch) vs one launch per colour
 	useFlowRegions = getenv("MI_FLOW_REGIONS") != nullptr;
 	if (const char* e = getenv("MI_FLOW_MAX")) flowMaxManifolds = (u32)atoi(e);
+	if (const char* e = getenv("MI_FLOW_EAGER")) flowEagerMax = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_HOP")) flowHopTicks = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_CAP")) flowBackoffCap = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_PREDICT")) flowPredictFrac = (u32)atoi(e);
