@@ -92,8 +92,9 @@ __global__ void __launch_bounds__(256) k_gather_sorted(u32 nc, u32 hashMask, con
 // Overlapping partners of the collider at sorted position t.  Every pair is produced exactly once, as (A = this collider,
 // B = partner): partners in the 13 "forward" neighbour cells, partners sorted before t in the own cell, and every large collider.
 // MODE_SLAB  : one traversal; the first PAIR_SLAB partners go to a per-collider slab, the full count to pairCount.
-// MODE_WRITE : second traversal writing directly at pairOffset[t] — only used in the rare step where some collider has more than
-//              PAIR_SLAB partners (the slab pass sets CTR_PAIR_OVERFLOW); same traversal order, so the pair list is identical.
+// MODE_WRITE : second traversal, ONLY of the colliders with more than PAIR_SLAB partners (the slab pass sets CTR_PAIR_OVERFLOW),
+//              writing directly at pairOffset[t]; same traversal order, so the pair list is identical.  Everybody else is packed
+//              from the slabs as usual.
 #define PAIR_SLAB 32
 enum { MODE_SLAB = 0, MODE_WRITE = 1 };
 template <int MODE>
@@ -106,6 +107,7 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* 
 	u32 nEnd = min(counters[CTR_FIRST_INACTIVE], nc);      // colliders behind this position have empty AABBs
 	u32 firstLarge = min(counters[CTR_FIRST_LARGE], nEnd);
 	if (t >= nEnd) { if (MODE == MODE_SLAB) pairCount[t] = 0; return; }
+	if (MODE == MODE_WRITE && pairCount[t] <= PAIR_SLAB) return; // complete in its slab
 	float4 amin = sMin[t], amax = sMax[t];
 	u32 me = __float_as_uint(amin.w);
 	u32 n = 0;
@@ -228,9 +230,8 @@ void launch_broadphase_write(World& w, u32 numPairs)
 {
 	u32 nc = w.nc;
 	if (!nc || !numPairs) return;
-	if (w.hCounters[CTR_PAIR_OVERFLOW]) // some collider has more than PAIR_SLAB partners: redo the traversal, writing in place
+	hipLaunchKernelGGL(k_pairs_pack, dim3((u32)(((size_t)nc * PAIR_SLAB + 255) / 256)), dim3(256), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.pairSlab.p, w.pairs.p, (u32)w.pairCap);
+	if (w.hCounters[CTR_PAIR_OVERFLOW]) // some colliders have more than PAIR_SLAB partners: those (only) repeat their traversal, writing in place
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_WRITE>), dim3((nc + 255) / 256), dim3(256), 0, w.stream, nc, w.hashTableSize - 1, w.sCellKey.p, w.sMin.p, w.sMax.p,
 			w.cellStart.p, w.cellEnd.p, w.dCounters.p, w.pairCount.p, w.pairOffset.p, w.pairs.p, (u32)w.pairCap);
-	else
-		hipLaunchKernelGGL(k_pairs_pack, dim3((u32)(((size_t)nc * PAIR_SLAB + 255) / 256)), dim3(256), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.pairSlab.p, w.pairs.p, (u32)w.pairCap);
 }

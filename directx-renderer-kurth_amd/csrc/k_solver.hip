@@ -29,11 +29,17 @@ __global__ void __launch_bounds__(256) k_active_list(u32* __restrict__ counters,
 	u32 m = blockIdx.x * blockDim.x + threadIdx.x;
 	uint4 ids = make_uint4(0, 0, 0, 0);
 	if (m < counters[CTR_NUM_VALID]) ids = manifolds[m].ids;
-	u32 total = ids.z; // contacts of this wave: one atomic per wave instead of one per manifold
+	u32 total = ids.z; // contacts of this wave
 	for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-	if ((threadIdx.x & 63) == 0 && total) atomicAdd(&counters[CTR_NUM_CONTACTS], total);
-	if (!ids.z) return;
-	u32 j = atomicAdd(&counters[CTR_NUM_ACTIVE], 1u); // wave-aggregated by the compiler
+	// one atomic pair per wave: lane 0 reserves the wave's range, the lanes take consecutive places in lane order
+	bool active = ids.z != 0;
+	u64 mask = __ballot(active);
+	u32 lane = threadIdx.x & 63u;
+	u32 base = 0;
+	if (lane == 0 && mask) { base = atomicAdd(&counters[CTR_NUM_ACTIVE], (u32)__popcll(mask)); atomicAdd(&counters[CTR_NUM_CONTACTS], total); }
+	base = __shfl(base, 0);
+	if (!active) return;
+	u32 j = base + (u32)__popcll(mask & ((1ull << lane) - 1ull));
 	actIds[j] = make_uint4(ids.x, ids.y, ids.z, m);
 	mColor[j] = UNCOLORED;
 }
@@ -84,6 +90,90 @@ __global__ void __launch_bounds__(256) k_color_round(u32* __restrict__ counters,
 	u64 key = claimKey(round, slot);
 	if (da) atomicMin((unsigned long long*)&cur[a], (unsigned long long)key);
 	if (db) atomicMin((unsigned long long*)&cur[b], (unsigned long long)key);
+}
+
+// All colouring rounds in ONE launch: the same rounds as k_color_round (identical claims, identical colours), separated by a grid
+// barrier (one agent-scope atomic per workgroup + a poll, ~2 us) instead of a kernel boundary (~10 us per round at 200k manifolds).
+// Lanes keep their manifolds across rounds (grid-stride with a fixed mapping), so mColor stays private to its lane; the per-body
+// words other workgroups read (claims, colour masks) go through agent-scope atomics.  The loop ends as soon as a round leaves
+// nothing uncoloured.  All workgroups must be resident (the launcher sizes the grid accordingly); the barrier spin is bounded.
+#define COLOR_BARRIER_SPINS (1u << 22)
+__global__ void __launch_bounds__(1024) k_color_all(u32* counters, u32 nb, u32 maxRounds, const uint4* __restrict__ actIds, u32* __restrict__ mColor,
+	u64* bodyMask, u64* claim)
+{
+	u32* bar = counters + CTR_COLOR_BARRIER;        // [0] arrivals (monotonic over the launch), [1..3] uncoloured manifolds left after round r % 3
+	const u32 n = counters[CTR_NUM_ACTIVE];
+	const u32 T = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x;
+	__shared__ u32 sLeft, sStop;
+	u32 lastUseful = 0;
+	for (u32 round = 0; round <= maxRounds; ++round)
+	{
+		if (threadIdx.x == 0) sLeft = 0;
+		__syncthreads();
+		u32 left = 0;
+		for (u32 j = tid; j < n; j += T)
+		{
+			if (mColor[j] != UNCOLORED) continue;
+			uint4 ids = actIds[j];
+			u32 a = ids.x, b = ids.y, slot = ids.w;
+			bool da = a < nb, db = b < nb;
+			bool colored = false;
+			if (round > 0)
+			{
+				const u64* prev = claim + (size_t)((round - 1) & 1) * nb;
+				u64 key = claimKey(round - 1, slot);
+				bool won = (!da || __hip_atomic_load(&prev[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key) && (!db || __hip_atomic_load(&prev[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key);
+				if (won)
+				{
+					u64 used = (da ? __hip_atomic_load(&bodyMask[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull) | (db ? __hip_atomic_load(&bodyMask[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull);
+					u64 freeMask = ~used;
+					u32 c;
+					if (freeMask == 0ull) { c = MI_SERIAL_COLOR; }
+					else
+					{
+						c = (u32)__ffsll((long long)freeMask) - 1;
+						if (da) atomicOr((unsigned long long*)&bodyMask[a], 1ull << c); // the only winner on this body in this round
+						if (db) atomicOr((unsigned long long*)&bodyMask[b], 1ull << c);
+					}
+					mColor[j] = c;
+					lastUseful = round;
+					colored = true;
+				}
+			}
+			if (!colored)
+			{
+				if (round == maxRounds) { mColor[j] = MI_SERIAL_COLOR; atomicAdd(&counters[CTR_OVERFLOW], 1u); }
+				else
+				{
+					u64* cur = claim + (size_t)(round & 1) * nb;
+					u64 key = claimKey(round, slot);
+					if (da) atomicMin((unsigned long long*)&cur[a], (unsigned long long)key);
+					if (db) atomicMin((unsigned long long*)&cur[b], (unsigned long long)key);
+					++left;
+				}
+			}
+		}
+		for (int o = 32; o > 0; o >>= 1) left += __shfl_xor(left, o);
+		if ((threadIdx.x & 63u) == 0u && left) atomicAdd(&sLeft, left);
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			if (sLeft) atomicAdd(&bar[1 + round % 3], sLeft);
+			if (blockIdx.x == 0) __hip_atomic_store(&bar[1 + (round + 1) % 3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // free since round - 2
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			atomicAdd(&bar[0], 1u);
+			u32 target = (round + 1) * gridDim.x, spins = 0;
+			while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+			{
+				__builtin_amdgcn_s_sleep(2);
+				if (++spins > COLOR_BARRIER_SPINS) { atomicOr(&counters[CTR_FLOW_STATUS], 8u); break; }
+			}
+			sStop = (__hip_atomic_load(&bar[1 + round % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u || spins > COLOR_BARRIER_SPINS) ? 1u : 0u;
+		}
+		__syncthreads();
+		if (sStop) break;
+	}
+	if (lastUseful) atomicMax(&counters[CTR_LAST_ROUND], lastUseful);
 }
 
 __global__ void __launch_bounds__(256) k_color_keys(const u32* __restrict__ counters, u32 numPairs, const uint4* __restrict__ actIds, const u32* __restrict__ mColor,
@@ -250,9 +340,26 @@ void launch_coloring(World& w, u32 numPairs)
 	// the active count is not known on the host yet: size the round launches by last step's count (+25 %), never above numPairs
 	u32 est = w.lastNumManifolds ? std::min<u32>(numPairs, w.lastNumManifolds + w.lastNumManifolds / 4 + 1024) : numPairs;
 	dim3 rgrid((est + 255) / 256);
-	u32 rounds = w.coloringRounds;
-	for (u32 r = 0; r <= rounds; ++r)
-		hipLaunchKernelGGL(k_color_round, (r == rounds) ? grid : rgrid, block, 0, w.stream, w.dCounters.p, nb, r, rounds, w.actIds.p, w.mColor.p, w.bodyMask.p, w.claim.p);
+	if (w.useFusedColoring)
+	{
+		// all rounds in one launch; every workgroup must be resident for the grid barrier (small kernel: 8 blocks per CU fit)
+		if (!w.colorMaxBlocks)
+		{
+			int perCU = 0, cus = 0;
+			MI_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, k_color_all, 1024, 0));
+			MI_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w.device));
+			w.colorMaxBlocks = (u32)std::max(1, std::min(perCU, 1)) * (u32)std::max(1, cus); // one 1024-lane workgroup per CU: few barrier arrivals
+		}
+		MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_COLOR_BARRIER, 0, 4 * sizeof(u32), w.stream));
+		u32 blocks = std::min<u32>(std::max(1u, (est + 1023) / 1024), w.colorMaxBlocks);
+		hipLaunchKernelGGL(k_color_all, dim3(blocks), dim3(1024), 0, w.stream, w.dCounters.p, nb, 1024u, w.actIds.p, w.mColor.p, w.bodyMask.p, w.claim.p);
+	}
+	else
+	{
+		u32 rounds = w.coloringRounds;
+		for (u32 r = 0; r <= rounds; ++r)
+			hipLaunchKernelGGL(k_color_round, (r == rounds) ? grid : rgrid, block, 0, w.stream, w.dCounters.p, nb, r, rounds, w.actIds.p, w.mColor.p, w.bodyMask.p, w.claim.p);
+	}
 	hipLaunchKernelGGL(k_color_keys, grid, block, 0, w.stream, w.dCounters.p, numPairs, w.actIds.p, w.mColor.p, w.mKey.p, w.mIdx.p);
 	prim_sort_pairs_u32(w, w.mKey.p, w.mKeySorted.p, w.mIdx.p, w.mOrder.p, numPairs, 10);
 	hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(512), 0, w.stream, w.dCounters.p, numPairs, w.mKeySorted.p);

@@ -75,6 +75,7 @@ enum
 	CTR_FLOW_PROBES = 14,   // dataflow sweep: number of record polls of the step (must directly follow CTR_FLOW_STATUS)
 	CTR_BUCKET_START = 16,  // 65 words: first slot of narrowphase bucket key b (tA*6+tB); [64] unused
 	CTR_KEY_START = 96,     // (MI_MAX_COLORS+1)*4 + 1 words: first schedule slot of key colour*4 + (4-count); last = numManifolds
+	CTR_COLOR_BARRIER = 360,// 4 words: grid barrier of the fused colouring kernel (arrivals, 3 x manifolds left)
 	CTR_FLOW_CENSUS = 368,  // 16 words: workgroups of the running dataflow launch per XCD [0..7], registered [8], finished [9]
 	CTR_REGION_START = 384, // 9 words: first position in flowOrder of XCD region r; [8] = numManifolds
 	CTR_REGION_CUTS = 400,  // 7 floats: region r holds bodies with cuts[r-1] <= x < cuts[r]
@@ -134,7 +135,8 @@ struct World
 
 	// settings snapshot for the running step
 	u32 iterations = 30;
-	u32 coloringRounds = 24;     // adaptive: last useful round of the previous step + margin
+	u32 coloringRounds = 24;     // adaptive: last useful round of the previous step + margin (launch-per-round colouring only)
+	bool useFusedColoring = true; u32 colorMaxBlocks = 0; // all colouring rounds in one launch with a grid barrier (MI_PHYSICS_NO_FUSED_COLORING=1: one launch per round)
 	u32 lastNumManifolds = 0;    // sizes the colouring-round launches of the next step
 	mi_stats stats = {};
 	std::vector<hipEvent_t> stageEvents;

@@ -49,6 +49,7 @@ World::World(int dev) : device(dev)
 	useGraph = getenv("MI_PHYSICS_NO_GRAPH") == nullptr; // rocprofv3's kernel trace needs plain launches
 	useFlow = getenv("MI_PHYSICS_NO_FLOW") == nullptr;   // dataflow contact sweep (one launch) vs one launch per colour
 	useFlowRegions = getenv("MI_FLOW_REGIONS") != nullptr;
+	useFusedColoring = getenv("MI_PHYSICS_NO_FUSED_COLORING") == nullptr;
 	if (const char* e = getenv("MI_FLOW_MAX")) flowMaxManifolds = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_EAGER")) flowEagerMax = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_HOP")) flowHopTicks = (u32)atoi(e);
@@ -478,7 +479,8 @@ int World::stepInternal(float dt, u32 iters)
 	if (hCounters[CTR_FLOW_STATUS])                        // the previous step's dataflow sweep gave up waiting: its result is invalid
 	{
 		useFlow = false;
-		fail(MI_ERR_HIP, "dataflow contact sweep gave up waiting (status " + std::to_string(hCounters[CTR_FLOW_STATUS]) + ": 1 = hand-over, 2 = census, 4 = unserved XCD region; GPU shared with another persistent kernel?); set MI_PHYSICS_NO_FLOW=1");
+		useFusedColoring = false;
+		fail(MI_ERR_HIP, "a persistent kernel gave up waiting (status " + std::to_string(hCounters[CTR_FLOW_STATUS]) + ": 1 = contact hand-over, 2 = XCD census, 4 = unserved XCD region, 8 = colouring barrier; GPU shared with another persistent kernel?); set MI_PHYSICS_NO_FLOW=1 MI_PHYSICS_NO_FUSED_COLORING=1");
 		return lastError;
 	}
 	stats.flowProbes = hCounters[CTR_FLOW_PROBES];
