@@ -25,11 +25,10 @@ MI_DEV void boxToAABB(V3 lo, V3 hi, Q4 rot, V3 tr, V3& mn, V3& mx)
 	growBox(mn, mx, rot * hi + tr);
 }
 
-__global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
+// Returns the largest AABB extent of the collider if it rides on a rigid body (the broadphase cell size is the maximum of those), else 0.
+MI_DEV float buildCollider(u32 i, u32 nb, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
 	const float4* __restrict__ colStaticPose, const uint8_t* __restrict__ simMask, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax)
 {
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= nc) return;
 	ColliderRec c = colLocal[i];
 	u32 type = colType(c), body = colBody(c);
 	if (body < nb && !simMask[body]) // body simulated by another GPU (spatial slabs): empty AABB, overlaps nothing
@@ -37,7 +36,7 @@ __global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const C
 		colWorld[i] = c;
 		aabbMin[i] = make_float4(MI_FLT_MAX, MI_FLT_MAX, MI_FLT_MAX, 0.f);
 		aabbMax[i] = make_float4(-MI_FLT_MAX, -MI_FLT_MAX, -MI_FLT_MAX, 0.f);
-		return;
+		return 0.f;
 	}
 	const float4* P = (body < nb) ? (pose + 2 * body) : (colStaticPose + 2 * i);
 	V3 tpos = v3f4(P[0]);
@@ -113,23 +112,39 @@ __global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const C
 	colWorld[i] = o;
 	aabbMin[i] = make_float4(mn.x, mn.y, mn.z, 0.f);
 	aabbMax[i] = make_float4(mx.x, mx.y, mx.z, 0.f);
+	return (body < nb) ? fmaxf(fmaxf(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z) : 0.f;
+}
+
+// One lane per collider; the kernel also produces the broadphase cell size (max extent; max() is order-independent, so the atomic is
+// deterministic; CTR_CELL_SIZE was reset at the end of the previous broadphase) and clears the grid's cell table.
+__global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
+	const float4* __restrict__ colStaticPose, const uint8_t* __restrict__ simMask, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax,
+	u32* __restrict__ counters, u32* __restrict__ cellStart, u32 hashTableSize)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	float e = (i < nc) ? buildCollider(i, nb, colLocal, pose, colStaticPose, simMask, colWorld, aabbMin, aabbMax) : 0.f;
+	for (int o = 32; o > 0; o >>= 1) e = fmaxf(e, __shfl_xor(e, o));
+	if ((threadIdx.x & 63) == 0 && e > 0.f) atomicMax(&counters[CTR_CELL_SIZE], __float_as_uint(e));
+	for (u32 h = i; h < hashTableSize; h += gridDim.x * blockDim.x) cellStart[h] = 0xFFFFFFFFu; // EMPTY_CELL
 }
 
 void launch_build_colliders(World& w)
 {
 	if (!w.nc) return;
 	hipLaunchKernelGGL(k_build_colliders, dim3((w.nc + 255) / 256), dim3(256), 0, w.stream, w.nc, w.nb, w.colLocal.p, w.pose.p, w.colStaticPose.p,
-		w.simMask.p, w.colWorld.p, w.aabbMin.p, w.aabbMax.p);
+		w.simMask.p, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.cellStart.p, w.hashTableSize);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K8: gravity + force integration, world inertia.  140 B read + 104 B write per body.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, const float4* __restrict__ pose, const float4* __restrict__ bprops,
-	const float4* __restrict__ force, const uint8_t* __restrict__ simMask, float4* __restrict__ vel, float4* __restrict__ cog, float4* __restrict__ invIw)
+	const float4* __restrict__ force, const uint8_t* __restrict__ simMask, float4* __restrict__ vel, float4* __restrict__ cog, float4* __restrict__ invIw,
+	u64* __restrict__ bodyMask, u64* __restrict__ claim)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > nb) return;
+	if (bodyMask) { bodyMask[i] = 0ull; claim[i] = ~0ull; claim[(size_t)nb + i] = ~0ull; } // per-body state of the colouring that follows (saves three fill launches)
 	if (i < nb && !simMask[i]) return;
 	if (i == nb) // static dummy (physics.cpp:1279)
 	{
@@ -170,7 +185,7 @@ __global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, cons
 void launch_integrate_forces(World& w, float dt)
 {
 	hipLaunchKernelGGL(k_integrate_forces, dim3((w.nb + 1 + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.force.p,
-		w.simMask.p, w.vel.p, w.cog.p, w.invIw.p);
+		w.simMask.p, w.vel.p, w.cog.p, w.invIw.p, flow_num_regions(w) > 1 ? nullptr : w.bodyMask.p, w.claim.p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -32,25 +32,11 @@ MI_DEV bool aabbOverlap(float4 amin, float4 amax, float4 bmin, float4 bmax)
 	return true;
 }
 
-// Largest extent among colliders that ride on a rigid body.  max() is order-independent, so the atomic is deterministic.
-__global__ void __launch_bounds__(256) k_max_extent(u32 nc, u32 nb, const ColliderRec* __restrict__ colWorld, const float4* __restrict__ aabbMin,
-	const float4* __restrict__ aabbMax, u32* __restrict__ counters)
-{
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	float e = 0.f;
-	if (i < nc && colBody(colWorld[i]) < nb)
-	{
-		float4 mn = aabbMin[i], mx = aabbMax[i];
-		e = fmaxf(fmaxf(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
-	}
-	for (int o = 32; o > 0; o >>= 1) e = fmaxf(e, __shfl_xor(e, o));
-	if ((threadIdx.x & 63) == 0 && e > 0.f) atomicMax(&counters[CTR_CELL_SIZE], __float_as_uint(e));
-}
-
 __global__ void __launch_bounds__(256) k_cell_assign(u32 nc, u32 hashMask, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
-	const u32* __restrict__ counters, u32* __restrict__ hashKey, u32* __restrict__ sortIdx)
+	u32* __restrict__ counters, u32* __restrict__ hashKey, u32* __restrict__ sortIdx)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i == 0) { counters[CTR_FIRST_LARGE] = 0xFFFFFFFFu; counters[CTR_FIRST_INACTIVE] = 0xFFFFFFFFu; counters[CTR_PAIR_OVERFLOW] = 0u; } // "none" until k_gather_sorted / k_pairs say otherwise
 	if (i >= nc) return;
 	float maxExtent = fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f);
 	float cell = maxExtent * 1.001f;
@@ -166,7 +152,11 @@ __global__ void __launch_bounds__(256) k_pairs_pack(u32 nc, const u32* __restric
 
 __global__ void k_finish_pair_count(u32 nc, const u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, u32* __restrict__ counters)
 {
-	if (threadIdx.x == 0 && blockIdx.x == 0) counters[CTR_NUM_PAIRS] = nc ? pairOffset[nc - 1] + pairCount[nc - 1] : 0;
+	if (threadIdx.x == 0 && blockIdx.x == 0)
+	{
+		counters[CTR_NUM_PAIRS] = nc ? pairOffset[nc - 1] + pairCount[nc - 1] : 0;
+		counters[CTR_CELL_SIZE] = 0; // nobody reads the cell size after the pair traversal: ready for the next step's atomicMax
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -209,17 +199,12 @@ void launch_broadphase_count(World& w)
 	if (!nc) return;
 	dim3 grid((nc + 255) / 256), block(256);
 	u32 H = w.hashTableSize, mask = H - 1;
-	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CELL_SIZE, 0, sizeof(u32), w.stream));
-	MI_CHECK(hipMemsetAsync(w.cellStart.p, 0xFF, sizeof(u32) * H, w.stream));
-	hipLaunchKernelGGL(k_max_extent, grid, block, 0, w.stream, nc, w.nb, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p);
+	// cell size (max extent) and the cleared cell table come out of k_build_colliders
 	hipLaunchKernelGGL(k_cell_assign, grid, block, 0, w.stream, nc, mask, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.hashKey.p, w.sortIdx.p);
 	prim_sort_pairs_u32(w, w.hashKey.p, w.hashKeySorted.p, w.sortIdx.p, w.sortIdxSorted.p, nc, log2ceil(H) + 1);
-	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_FIRST_LARGE, 0xFF, sizeof(u32), w.stream));    // "none": kernels clamp to nc
-	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_FIRST_INACTIVE, 0xFF, sizeof(u32), w.stream));
 	hipLaunchKernelGGL(k_gather_sorted, grid, block, 0, w.stream, nc, mask, w.hashKeySorted.p, w.sortIdxSorted.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p,
 		w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p);
 	w.pairSlab.ensure((size_t)nc * PAIR_SLAB, w.stream);
-	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_PAIR_OVERFLOW, 0, sizeof(u32), w.stream));
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_SLAB>), grid, block, 0, w.stream, nc, mask, w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p, w.dCounters.p,
 		w.pairCount.p, w.pairOffset.p, w.pairSlab.p, 0u);
 	prim_exclusive_scan_u32(w, w.pairCount.p, w.pairOffset.p, nc);

@@ -27,6 +27,11 @@ MI_DEV u64 claimKey(u32 round, u32 slot) { return ((u64)(0xFFFFu - round) << 48)
 __global__ void __launch_bounds__(256) k_active_list(u32* __restrict__ counters, const ManifoldRec* __restrict__ manifolds, uint4* __restrict__ actIds, u32* __restrict__ mColor)
 {
 	u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+	if (m == 0) // state of the colouring that follows (nobody else touches these words in this kernel)
+	{
+		counters[CTR_LAST_ROUND] = 0; counters[CTR_OVERFLOW] = 0;
+		for (u32 i = 0; i < 4; ++i) counters[CTR_COLOR_BARRIER + i] = 0;
+	}
 	uint4 ids = make_uint4(0, 0, 0, 0);
 	if (m < counters[CTR_NUM_VALID]) ids = manifolds[m].ids;
 	u32 total = ids.z; // contacts of this wave
@@ -333,9 +338,11 @@ void launch_coloring(World& w, u32 numPairs)
 		MI_CHECK(hipMemsetAsync(w.regMask.p, 0, sizeof(u32) * (nb + 1), w.stream));
 	}
 	else w.regionsReady = false;
-	MI_CHECK(hipMemsetAsync(w.bodyMask.p, 0, sizeof(u64) * (nb + 1), w.stream));
-	MI_CHECK(hipMemsetAsync(w.claim.p, 0xFF, sizeof(u64) * 2 * (nb + 1), w.stream));
-	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_LAST_ROUND, 0, 2 * sizeof(u32), w.stream));
+	if (flow_num_regions(w) > 1) // otherwise k_integrate_forces has cleared both while it was touching every body anyway
+	{
+		MI_CHECK(hipMemsetAsync(w.bodyMask.p, 0, sizeof(u64) * (nb + 1), w.stream));
+		MI_CHECK(hipMemsetAsync(w.claim.p, 0xFF, sizeof(u64) * 2 * (nb + 1), w.stream));
+	}
 	hipLaunchKernelGGL(k_active_list, grid, block, 0, w.stream, w.dCounters.p, w.manifolds.p, w.actIds.p, w.mColor.p);
 	// the active count is not known on the host yet: size the round launches by last step's count (+25 %), never above numPairs
 	u32 est = w.lastNumManifolds ? std::min<u32>(numPairs, w.lastNumManifolds + w.lastNumManifolds / 4 + 1024) : numPairs;
@@ -350,7 +357,6 @@ void launch_coloring(World& w, u32 numPairs)
 			MI_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w.device));
 			w.colorMaxBlocks = (u32)std::max(1, std::min(perCU, 1)) * (u32)std::max(1, cus); // one 1024-lane workgroup per CU: few barrier arrivals
 		}
-		MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_COLOR_BARRIER, 0, 4 * sizeof(u32), w.stream));
 		u32 blocks = std::min<u32>(std::max(1u, (est + 1023) / 1024), w.colorMaxBlocks);
 		hipLaunchKernelGGL(k_color_all, dim3(blocks), dim3(1024), 0, w.stream, w.dCounters.p, nb, 1024u, w.actIds.p, w.mColor.p, w.bodyMask.p, w.claim.p);
 	}

@@ -492,8 +492,8 @@ int World::stepInternal(float dt, u32 iters)
 	launch_narrowphase(*this, numPairs);
 	if (T) MI_CHECK(hipEventRecord(stageEvents[2], stream));
 
-	launch_integrate_forces(*this, dt);
 	flow_choose_regions(*this);
+	launch_integrate_forces(*this, dt);
 	launch_coloring(*this, numPairs);
 	launch_contact_init(*this, numPairs, dt);
 	launch_joint_init(*this, dt);
