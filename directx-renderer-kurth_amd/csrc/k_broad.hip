@@ -77,66 +77,78 @@ __global__ void __launch_bounds__(256) k_gather_sorted(u32 nc, u32 hashMask, con
 
 // Overlapping partners of the collider at sorted position t.  Every pair is produced exactly once, as (A = this collider,
 // B = partner): partners in the 13 "forward" neighbour cells, partners sorted before t in the own cell, and every large collider.
-// MODE_SLAB  : one traversal; the first PAIR_SLAB partners go to a per-collider slab, the full count to pairCount.
-// MODE_WRITE : second traversal, ONLY of the colliders with more than PAIR_SLAB partners (the slab pass sets CTR_PAIR_OVERFLOW),
-//              writing directly at pairOffset[t]; same traversal order, so the pair list is identical.  Everybody else is packed
-//              from the slabs as usual.
+// SIXTEEN lanes work on one collider: lane g < 14 visits neighbour cell 13 + g, lane 14 the list of large colliders (a large
+// collider itself: lane 0 tests the large colliders before it).  Each lane counts its hits, a 16-lane prefix sum places them —
+// cell after cell, candidate after candidate, exactly the order one lane visiting everything would produce — and a second visit
+// writes them.  (One lane per collider left 6 waves per CU chasing 14 dependent hash -> range -> AABB chains each: 150 us at 100k.)
+// MODE_SLAB  : the first PAIR_SLAB partners go to a per-collider slab, the full count to pairCount.
+// MODE_WRITE : ONLY the colliders with more than PAIR_SLAB partners (the slab pass sets CTR_PAIR_OVERFLOW) repeat the visit,
+//              writing directly at pairOffset[t]; same order, so the pair list is identical.  Everybody else is packed from the slabs.
 #define PAIR_SLAB 32
+#define PAIR_LANES 16
 enum { MODE_SLAB = 0, MODE_WRITE = 1 };
 template <int MODE>
 __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* __restrict__ sCellKey, const float4* __restrict__ sMin, const float4* __restrict__ sMax,
 	const u32* __restrict__ cellStart, const u32* __restrict__ cellEnd, u32* __restrict__ counters,
 	u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, uint2* __restrict__ out, u32 pairCap)
 {
-	u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= nc) return;
+	u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+	u32 t = gid / PAIR_LANES, g = gid % PAIR_LANES;
+	bool valid = t < nc;
 	u32 nEnd = min(counters[CTR_FIRST_INACTIVE], nc);      // colliders behind this position have empty AABBs
 	u32 firstLarge = min(counters[CTR_FIRST_LARGE], nEnd);
-	if (t >= nEnd) { if (MODE == MODE_SLAB) pairCount[t] = 0; return; }
-	if (MODE == MODE_WRITE && pairCount[t] <= PAIR_SLAB) return; // complete in its slab
-	float4 amin = sMin[t], amax = sMax[t];
-	u32 me = __float_as_uint(amin.w);
-	u32 n = 0;
-	size_t base = (MODE == MODE_WRITE) ? (size_t)pairOffset[t] : (size_t)t * PAIR_SLAB;
-	u32 room = (MODE == MODE_WRITE) ? 0xFFFFFFFFu : PAIR_SLAB;
-#define EMIT(PARTNER) { if (n < room && (MODE == MODE_SLAB || base + n < pairCap)) out[base + n] = make_uint2(me, (PARTNER)); ++n; }
-
-	if (t >= firstLarge)
+	bool live = valid && t < nEnd;
+	if (MODE == MODE_WRITE) live = live && pairCount[t] > PAIR_SLAB; // everybody else is complete in its slab
+	float4 amin = make_float4(0.f, 0.f, 0.f, 0.f), amax = amin;
+	u32 me = 0;
+	// this lane's candidate range [s, e) and what a candidate must match
+	u32 s = 0, e = 0; u64 nkey = 0; bool checkKey = false;
+	if (live)
 	{
-		for (u32 u = firstLarge; u < t; ++u)
+		amin = sMin[t]; amax = sMax[t];
+		me = __float_as_uint(amin.w);
+		if (t >= firstLarge) { if (g == 0) { s = firstLarge; e = t; } }
+		else if (g == 14) { s = firstLarge; e = nEnd; }
+		else if (g < 14)
 		{
-			float4 bmin = sMin[u], bmax = sMax[u];
-			if (aabbOverlap(amin, amax, bmin, bmax)) EMIT(__float_as_uint(bmin.w))
-		}
-	}
-	else
-	{
-		u64 key = sCellKey[t];
-		i32 ix = (i32)(key & CELL_MASK), iy = (i32)((key >> 21) & CELL_MASK), iz = (i32)((key >> 42) & CELL_MASK);
-		for (i32 o = 13; o < 27; ++o) // offsets (dz,dy,dx) >= (0,0,0) in lexicographic order: own cell first, then the forward half
-		{
+			u64 key = sCellKey[t];
+			i32 ix = (i32)(key & CELL_MASK), iy = (i32)((key >> 21) & CELL_MASK), iz = (i32)((key >> 42) & CELL_MASK);
+			i32 o = 13 + (i32)g; // offsets (dz,dy,dx) >= (0,0,0) in lexicographic order: own cell first, then the forward half
 			i32 dz = o / 9 - 1, dy = (o / 3) % 3 - 1, dx = o % 3 - 1;
-			u64 nkey = packCell(ix + dx, iy + dy, iz + dz);
+			nkey = packCell(ix + dx, iy + dy, iz + dz);
 			u32 h = hashCell(nkey, hashMask);
-			u32 s = cellStart[h];
-			if (s == EMPTY_CELL) continue;
-			u32 e = cellEnd[h];
-			if (o == 13) e = min(e, t); // own cell: only partners sorted before me
-			for (u32 u = s; u < e; ++u)
+			u32 cs = cellStart[h];
+			if (cs != EMPTY_CELL)
 			{
-				if (sCellKey[u] != nkey) continue; // other cell sharing the hash bucket
-				float4 bmin = sMin[u], bmax = sMax[u];
-				if (aabbOverlap(amin, amax, bmin, bmax)) EMIT(__float_as_uint(bmin.w))
+				s = cs; e = cellEnd[h];
+				if (g == 0) e = min(e, t); // own cell: only partners sorted before me
+				checkKey = true;           // other cells may share the hash bucket
 			}
 		}
-		for (u32 u = firstLarge; u < nEnd; ++u)
-		{
-			float4 bmin = sMin[u], bmax = sMax[u];
-			if (aabbOverlap(amin, amax, bmin, bmax)) EMIT(__float_as_uint(bmin.w))
-		}
 	}
-#undef EMIT
-	if (MODE == MODE_SLAB) { pairCount[t] = n; if (n > PAIR_SLAB) counters[CTR_PAIR_OVERFLOW] = 1; }
+	u32 n = 0;
+	for (u32 u = s; u < e; ++u)
+	{
+		if (checkKey && sCellKey[u] != nkey) continue;
+		if (aabbOverlap(amin, amax, sMin[u], sMax[u])) ++n;
+	}
+	// exclusive prefix over the 16 lanes of the group (the groups of a wave are aligned to 16 lanes)
+	u32 incl = n;
+	for (u32 d = 1; d < PAIR_LANES; d <<= 1) { u32 v = __shfl_up(incl, d, PAIR_LANES); if (g >= d) incl += v; }
+	u32 total = __shfl(incl, PAIR_LANES - 1, PAIR_LANES);
+	u32 pos = incl - n;
+	if (MODE == MODE_SLAB && valid && g == 0) { pairCount[t] = live ? total : 0; if (total > PAIR_SLAB) counters[CTR_PAIR_OVERFLOW] = 1; }
+	if (!n) return;
+	size_t base = (MODE == MODE_WRITE) ? (size_t)pairOffset[t] : (size_t)t * PAIR_SLAB;
+	u32 room = (MODE == MODE_WRITE) ? 0xFFFFFFFFu : PAIR_SLAB;
+	for (u32 u = s; u < e; ++u)
+	{
+		if (checkKey && sCellKey[u] != nkey) continue;
+		float4 bmin = sMin[u];
+		if (!aabbOverlap(amin, amax, bmin, sMax[u])) continue;
+		if (pos < room && (MODE == MODE_SLAB || base + pos < pairCap)) out[base + pos] = make_uint2(me, __float_as_uint(bmin.w));
+		++pos;
+	}
 }
 
 // Packs the per-collider slabs into the dense, deterministic pair list (order: sorted position, then traversal order).
@@ -205,7 +217,7 @@ void launch_broadphase_count(World& w)
 	hipLaunchKernelGGL(k_gather_sorted, grid, block, 0, w.stream, nc, mask, w.hashKeySorted.p, w.sortIdxSorted.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p,
 		w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p);
 	w.pairSlab.ensure((size_t)nc * PAIR_SLAB, w.stream);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_SLAB>), grid, block, 0, w.stream, nc, mask, w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p, w.dCounters.p,
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_SLAB>), dim3((u32)(((size_t)nc * PAIR_LANES + 255) / 256)), block, 0, w.stream, nc, mask, w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p, w.dCounters.p,
 		w.pairCount.p, w.pairOffset.p, w.pairSlab.p, 0u);
 	prim_exclusive_scan_u32(w, w.pairCount.p, w.pairOffset.p, nc);
 	hipLaunchKernelGGL(k_finish_pair_count, dim3(1), dim3(64), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.dCounters.p);
@@ -217,6 +229,6 @@ void launch_broadphase_write(World& w, u32 numPairs)
 	if (!nc || !numPairs) return;
 	hipLaunchKernelGGL(k_pairs_pack, dim3((u32)(((size_t)nc * PAIR_SLAB + 255) / 256)), dim3(256), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.pairSlab.p, w.pairs.p, (u32)w.pairCap);
 	if (w.hCounters[CTR_PAIR_OVERFLOW]) // some colliders have more than PAIR_SLAB partners: those (only) repeat their traversal, writing in place
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_WRITE>), dim3((nc + 255) / 256), dim3(256), 0, w.stream, nc, w.hashTableSize - 1, w.sCellKey.p, w.sMin.p, w.sMax.p,
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_WRITE>), dim3((u32)(((size_t)nc * PAIR_LANES + 255) / 256)), dim3(256), 0, w.stream, nc, w.hashTableSize - 1, w.sCellKey.p, w.sMin.p, w.sMax.p,
 			w.cellStart.p, w.cellEnd.p, w.dCounters.p, w.pairCount.p, w.pairOffset.p, w.pairs.p, (u32)w.pairCap);
 }
