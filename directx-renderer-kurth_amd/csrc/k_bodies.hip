@@ -124,7 +124,12 @@ __global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const C
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	float e = (i < nc) ? buildCollider(i, nb, colLocal, pose, colStaticPose, simMask, colWorld, aabbMin, aabbMax) : 0.f;
 	for (int o = 32; o > 0; o >>= 1) e = fmaxf(e, __shfl_xor(e, o));
-	if ((threadIdx.x & 63) == 0 && e > 0.f) atomicMax(&counters[CTR_CELL_SIZE], __float_as_uint(e));
+	__shared__ u32 sMax; // one global atomic per workgroup (same-address atomics serialise)
+	if (threadIdx.x == 0) sMax = 0;
+	__syncthreads();
+	if ((threadIdx.x & 63) == 0 && e > 0.f) atomicMax(&sMax, __float_as_uint(e));
+	__syncthreads();
+	if (threadIdx.x == 0 && sMax) atomicMax(&counters[CTR_CELL_SIZE], sMax);
 	for (u32 h = i; h < hashTableSize; h += gridDim.x * blockDim.x) cellStart[h] = 0xFFFFFFFFu; // EMPTY_CELL
 }
 

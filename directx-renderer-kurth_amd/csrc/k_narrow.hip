@@ -1013,7 +1013,7 @@ void launch_narrowphase(World& w, u32 numPairs)
 	dim3 grid((numPairs + 255) / 256), block(256);
 	hipLaunchKernelGGL(k_classify, grid, block, 0, w.stream, w.dCounters.p, w.nb, w.pairs.p, w.colWorld.p, w.pairKey.p, (u64*)w.pairsSorted.p + numPairs);
 	// sort (bucket key, packed pair): unsorted packed pairs live in the upper half of pairsSorted, sorted ones in the lower half
-	prim_sort_pairs_u32_u64(w, w.pairKey.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p + numPairs, (u64*)w.pairsSorted.p, numPairs, 6);
+	csort_pairs_u64(w, w.pairKey.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p + numPairs, (u64*)w.pairsSorted.p, numPairs, 64);
 	hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p);
 	const u64* sortedPairs = (const u64*)w.pairsSorted.p;
 	hipLaunchKernelGGL(k_gjk, grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p);

@@ -15,7 +15,7 @@
 void prim_sort_pairs_u32(World& w, const u32* kin, u32* kout, const u32* vin, u32* vout, u32 n, u32 bits);
 
 #define UNCOLORED 0xFFFFFFFFu
-#define KEY_INACTIVE 0x3FFu
+#define KEY_INACTIVE (MI_NUM_SCHEDULE_KEYS + 3u) // sorts behind every schedule key; 264 buckets
 MI_DEV u32 hash32(u32 x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 // later rounds and (pseudo-random) higher priority => smaller key; the manifold slot makes keys unique and order-independent
 MI_DEV u64 claimKey(u32 round, u32 slot) { return ((u64)(0xFFFFu - round) << 48) | ((u64)(hash32(slot * 2654435761u + round) & 0xFFFFFFu) << 24) | (u64)(slot & 0xFFFFFFu); }
@@ -24,27 +24,34 @@ MI_DEV u64 claimKey(u32 round, u32 slot) { return ((u64)(0xFFFFu - round) << 48)
 // Active list: manifolds with at least one contact, appended with one wave-aggregated atomic per wave.  The list order is
 // arbitrary; nothing downstream depends on it (claims are keyed by slot, a colour's members are mutually independent).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_active_list(u32* __restrict__ counters, const ManifoldRec* __restrict__ manifolds, uint4* __restrict__ actIds, u32* __restrict__ mColor)
+__global__ void __launch_bounds__(1024) k_active_list(u32* __restrict__ counters, const ManifoldRec* __restrict__ manifolds, uint4* __restrict__ actIds, u32* __restrict__ mColor)
 {
+	// ONE pair of global atomics per 1024-lane workgroup: same-address atomics from all over the chip serialise (two per wave cost
+	// 100 us at 500k candidate pairs).  Waves reserve their ranges in an LDS counter, lane 0 of the workgroup reserves the global range.
+	__shared__ u32 sCount, sContacts, sBase;
 	u32 m = blockIdx.x * blockDim.x + threadIdx.x;
 	if (m == 0) // state of the colouring that follows (nobody else touches these words in this kernel)
 	{
 		counters[CTR_LAST_ROUND] = 0; counters[CTR_OVERFLOW] = 0;
 		for (u32 i = 0; i < 4; ++i) counters[CTR_COLOR_BARRIER + i] = 0;
 	}
+	if (threadIdx.x == 0) { sCount = 0; sContacts = 0; }
+	__syncthreads();
 	uint4 ids = make_uint4(0, 0, 0, 0);
 	if (m < counters[CTR_NUM_VALID]) ids = manifolds[m].ids;
 	u32 total = ids.z; // contacts of this wave
 	for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-	// one atomic pair per wave: lane 0 reserves the wave's range, the lanes take consecutive places in lane order
 	bool active = ids.z != 0;
 	u64 mask = __ballot(active);
 	u32 lane = threadIdx.x & 63u;
-	u32 base = 0;
-	if (lane == 0 && mask) { base = atomicAdd(&counters[CTR_NUM_ACTIVE], (u32)__popcll(mask)); atomicAdd(&counters[CTR_NUM_CONTACTS], total); }
-	base = __shfl(base, 0);
+	u32 waveBase = 0;
+	if (lane == 0 && mask) { waveBase = atomicAdd(&sCount, (u32)__popcll(mask)); atomicAdd(&sContacts, total); }
+	waveBase = __shfl(waveBase, 0);
+	__syncthreads();
+	if (threadIdx.x == 0 && sCount) { sBase = atomicAdd(&counters[CTR_NUM_ACTIVE], sCount); atomicAdd(&counters[CTR_NUM_CONTACTS], sContacts); }
+	__syncthreads();
 	if (!active) return;
-	u32 j = base + (u32)__popcll(mask & ((1ull << lane) - 1ull));
+	u32 j = sBase + waveBase + (u32)__popcll(mask & ((1ull << lane) - 1ull));
 	actIds[j] = make_uint4(ids.x, ids.y, ids.z, m);
 	mColor[j] = UNCOLORED;
 }
@@ -343,7 +350,7 @@ void launch_coloring(World& w, u32 numPairs)
 		MI_CHECK(hipMemsetAsync(w.bodyMask.p, 0, sizeof(u64) * (nb + 1), w.stream));
 		MI_CHECK(hipMemsetAsync(w.claim.p, 0xFF, sizeof(u64) * 2 * (nb + 1), w.stream));
 	}
-	hipLaunchKernelGGL(k_active_list, grid, block, 0, w.stream, w.dCounters.p, w.manifolds.p, w.actIds.p, w.mColor.p);
+	hipLaunchKernelGGL(k_active_list, dim3((numPairs + 1023) / 1024), dim3(1024), 0, w.stream, w.dCounters.p, w.manifolds.p, w.actIds.p, w.mColor.p);
 	// the active count is not known on the host yet: size the round launches by last step's count (+25 %), never above numPairs
 	u32 est = w.lastNumManifolds ? std::min<u32>(numPairs, w.lastNumManifolds + w.lastNumManifolds / 4 + 1024) : numPairs;
 	dim3 rgrid((est + 255) / 256);
@@ -367,7 +374,7 @@ void launch_coloring(World& w, u32 numPairs)
 			hipLaunchKernelGGL(k_color_round, (r == rounds) ? grid : rgrid, block, 0, w.stream, w.dCounters.p, nb, r, rounds, w.actIds.p, w.mColor.p, w.bodyMask.p, w.claim.p);
 	}
 	hipLaunchKernelGGL(k_color_keys, grid, block, 0, w.stream, w.dCounters.p, numPairs, w.actIds.p, w.mColor.p, w.mKey.p, w.mIdx.p);
-	prim_sort_pairs_u32(w, w.mKey.p, w.mKeySorted.p, w.mIdx.p, w.mOrder.p, numPairs, 10);
+	csort_pairs_u32(w, w.mKey.p, w.mKeySorted.p, w.mIdx.p, w.mOrder.p, numPairs, KEY_INACTIVE + 1);
 	hipLaunchKernelGGL(k_color_offsets, dim3(1), dim3(512), 0, w.stream, w.dCounters.p, numPairs, w.mKeySorted.p);
 }
 

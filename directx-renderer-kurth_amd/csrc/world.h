@@ -130,6 +130,7 @@ struct World
 	bool useFlow = true;                  // MI_PHYSICS_NO_FLOW=1: launch-per-colour sweep only
 	u32 flowHopTicks = 100, flowBackoffCap = 64, flowPredictFrac = 192; // poll pacing: 10 ns ticks; fraction (/256) of the iteration period slept through (MI_FLOW_HOP / _CAP / _PREDICT)
 	DevBuf<uint8_t> tempStorage;
+	DevBuf<u32> sortHist;                 // counting sort: per-tile bucket histograms + their scan
 	DevBuf<u32> dCounters; u32* hCounters = nullptr; // CTR_WORDS words each
 	size_t pairCap = 0, rowCap = 0;
 
@@ -183,3 +184,5 @@ void launch_joint_solve_iteration(World& w);
 void launch_copy_pose0(World& w);
 void launch_lerp_pose(World& w, float t);
 size_t primitives_temp_bytes(size_t maxItems);
+void csort_pairs_u32(World& w, const u32* keys, u32* keysOut, const u32* vals, u32* valsOut, u32 n, u32 numBuckets); // stable, keys < numBuckets <= 272
+void csort_pairs_u64(World& w, const u32* keys, u32* keysOut, const u64* vals, u64* valsOut, u32 n, u32 numBuckets);
