@@ -46,6 +46,18 @@ def cpu_baseline(scene, transforms, velocities, seconds=12.0, max_steps=40):
                       "the reference binary itself cannot be built (MSVC/Windows) and its u16 indices cannot hold this config" % (n, contacts)}
 
 
+def pmc_traffic(contacts, flow):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/), scaled to this run's contact count."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_k_solve_flow.json" if flow else "r01_pmc_k_solve_color.json")
+    try:
+        with open(path) as f:
+            p = json.load(f)
+        per_contact = (2.0 * p["fetch_size_kib_per_launch"] + p["write_size_kib_per_launch"]) * 1024.0 / p["contacts_per_step"]
+        return per_contact * contacts, os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +133,7 @@ def main():
         bytes_per_step = ALGORITHMIC_BYTES_PER_CONTACT_ITERATION * contacts * 30.0
         solve_s = mean["msSolve"] * 1e-3
         achieved = bytes_per_step / solve_s / 1e9 if solve_s > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(contacts, flow)
         out = {
             "metric": "physics steps/sec at 100k rigid bodies" if args.workload == "c3" else "physics steps/sec", "value": K / elapsed, "unit": "steps/s",
             "n_gpus": world_size, "steps": K, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -131,7 +144,7 @@ def main():
                        "parallelism": "1 gpu" if world_size == 1 else "%d spatial slabs + ghost-body halo over RCCL" % world_size},
             "stage_ms": {k: round(mean[k], 4) for k in ("msCollidersBroad", "msNarrow", "msSolverSetup", "msSolve", "msIntegrate", "msTotal")},
             "roofline": {"bound": "hbm", "kernel": "k_solve_flow (contact PGS sweep, 30 iterations, dataflow)" if flow else "k_solve_color (contact PGS sweep, one launch per colour and iteration)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_step / launches_per_step, "avg_launch_us": solve_s / launches_per_step * 1e6,
                          "launches_per_step": launches_per_step},
         }
