@@ -57,7 +57,7 @@ class Stats(C.Structure):
 
 
 EXPORTED_SYMBOLS = [
-    "mi_world_create", "mi_world_destroy", "mi_last_error", "mi_add_body", "mi_add_collider", "mi_add_static_collider",
+    "mi_world_create", "mi_world_destroy", "mi_last_error", "mi_add_body", "mi_add_hull_geometry", "mi_add_collider", "mi_add_static_collider",
     "mi_add_distance_constraint_local", "mi_add_distance_constraint_global", "mi_add_ball_constraint_local", "mi_add_ball_constraint_global",
     "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
     "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_apply_force_torque", "mi_set_velocity",
@@ -140,6 +140,11 @@ class World:
     # ---- add API ------------------------------------------------------------------------------------------
     def add_body(self, pos, rot=(0, 0, 0, 1), kinematic=False, gravity_factor=1.0, linear_damping=0.4, angular_damping=0.4):
         return self._id(self.lib.mi_add_body(self.w, int(kinematic), C.c_float(gravity_factor), C.c_float(linear_damping), C.c_float(angular_damping), _f(pos), _f(rot)))
+
+    def add_hull_geometry(self, vertices, triangles):
+        """bounding_hull_geometry::fromMesh (reference bounding_volumes.cpp:1394-1452): convex vertex set + outward-facing triangles."""
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3); t = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        return self._id(self.lib.mi_add_hull_geometry(self.w, _f(v), C.c_uint32(len(v)), t.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(len(t))))
 
     def add_collider(self, body, ctype, shape, material):
         s = np.zeros(10, np.float32); s[:len(shape)] = shape

@@ -27,7 +27,8 @@ MI_DEV void boxToAABB(V3 lo, V3 hi, Q4 rot, V3 tr, V3& mn, V3& mx)
 
 // Returns the largest AABB extent of the collider if it rides on a rigid body (the broadphase cell size is the maximum of those), else 0.
 MI_DEV float buildCollider(u32 i, u32 nb, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
-	const float4* __restrict__ colStaticPose, const uint8_t* __restrict__ simMask, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax)
+	const float4* __restrict__ colStaticPose, const uint8_t* __restrict__ simMask, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax,
+	const float4* __restrict__ hullInfo)
 {
 	ColliderRec c = colLocal[i];
 	u32 type = colType(c), body = colBody(c);
@@ -107,6 +108,18 @@ MI_DEV float buildCollider(u32 i, u32 nb, const ColliderRec* __restrict__ colLoc
 			o.a = make_float4(wq.x, wq.y, wq.z, wq.w);
 			o.b = make_float4(wc.x, wc.y, wc.z, radius.x);
 		} break;
+		case MI_HULL: // physics.cpp:742-753: compose the transforms, AABB = the geometry's local box transformed
+		{
+			Q4 hq = q4f4(c.a);
+			V3 hp = v3(c.b.x, c.b.y, c.b.z);
+			u32 g = (u32)c.b.w;
+			Q4 rotation = trot * hq;
+			V3 position = trot * hp + tpos;
+			float4 lo = hullInfo[2 * g], hi = hullInfo[2 * g + 1];
+			boxToAABB(v3f4(lo), v3f4(hi), rotation, position, mn, mx);
+			o.a = make_float4(rotation.x, rotation.y, rotation.z, rotation.w);
+			o.b = make_float4(position.x, position.y, position.z, c.b.w);
+		} break;
 		default: mn = v3s(0.f); mx = v3s(0.f); break;
 	}
 	colWorld[i] = o;
@@ -119,10 +132,10 @@ MI_DEV float buildCollider(u32 i, u32 nb, const ColliderRec* __restrict__ colLoc
 // deterministic; CTR_CELL_SIZE was reset at the end of the previous broadphase) and clears the grid's cell table.
 __global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
 	const float4* __restrict__ colStaticPose, const uint8_t* __restrict__ simMask, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax,
-	u32* __restrict__ counters, u32* __restrict__ cellStart, u32 hashTableSize)
+	u32* __restrict__ counters, u32* __restrict__ cellStart, u32 hashTableSize, const float4* __restrict__ hullInfo)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	float e = (i < nc) ? buildCollider(i, nb, colLocal, pose, colStaticPose, simMask, colWorld, aabbMin, aabbMax) : 0.f;
+	float e = (i < nc) ? buildCollider(i, nb, colLocal, pose, colStaticPose, simMask, colWorld, aabbMin, aabbMax, hullInfo) : 0.f;
 	for (int o = 32; o > 0; o >>= 1) e = fmaxf(e, __shfl_xor(e, o));
 	__shared__ u32 sMax; // one global atomic per workgroup (same-address atomics serialise)
 	if (threadIdx.x == 0) sMax = 0;
@@ -137,7 +150,7 @@ void launch_build_colliders(World& w)
 {
 	if (!w.nc) return;
 	hipLaunchKernelGGL(k_build_colliders, dim3((w.nc + 255) / 256), dim3(256), 0, w.stream, w.nc, w.nb, w.colLocal.p, w.pose.p, w.colStaticPose.p,
-		w.simMask.p, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.cellStart.p, w.hashTableSize);
+		w.simMask.p, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.cellStart.p, w.hashTableSize, w.hullInfo.p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -2,7 +2,8 @@
 // group of type pairs: closed forms (:374-612, :1074-1140), box-box SAT + Sutherland-Hodgman clipping (:1179-1527) and
 // GJK + EPA for capsule / cylinder vs box and cylinder vs cylinder (:705-790, :821-1043, collision_gjk.{h,cpp}, collision_epa.{h,cpp}).
 // One thread per candidate pair; every pair writes a 96-byte ManifoldRec (count 0 = no collision) so contact generation needs no
-// atomics and keeps pair order.  Hull pairs are not built.
+// atomics and keeps pair order.  Every pair with a convex hull is GJK + EPA with one contact (:496-520, 792-818, 1045-1071, 1150-1176,
+// 1529-1584); the hull's support function walks its vertex list (collision_gjk.h:77-100).
 #include "world.h"
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
@@ -13,7 +14,7 @@ void prim_sort_pairs_u32_u64(World& w, const u32* kin, u32* kout, const u64* vin
 
 struct Man { V3 n; float4 p[4]; u32 count; };
 
-MI_DEV bool typeSupported(u32 t) { return t <= MI_OBB; }
+MI_DEV bool typeSupported(u32 t) { return t <= MI_HULL; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K5: prune + classify.  Reads the 16-B tag quarter of both colliders.
@@ -584,13 +585,41 @@ MI_DEV V3 cylinderSupport(const Capsule& c, V3 dir) // collision_gjk.h:30-46
 	return farther + projectedDir * c.r;
 }
 MI_DEV V3 boxSupport(const Box& b, V3 dir) { return v3((dir.x < 0.f) ? b.lo.x : b.hi.x, (dir.y < 0.f) ? b.lo.y : b.hi.y, (dir.z < 0.f) ? b.lo.z : b.hi.z); }
-// The two convex shapes of one GJK/EPA instance: A is a tube (capsule or cylinder), B an axis-aligned box or a cylinder.
-struct SupShapes { Capsule tubeA, tubeB; Box box; bool aIsCylinder, bIsCylinder; };
+struct Hull { Q4 q; V3 pos; u32 first, count; };
+MI_DEV V3 hullSupport(const Hull& h, const float4* __restrict__ hullVerts, V3 dir) // collision_gjk.h:77-100: first vertex with the largest dot product
+{
+	dir = conjugate(h.q) * dir;
+	V3 result = v3s(0.f);
+	float maxDist = -MI_FLT_MAX;
+	for (u32 i = 0; i < h.count; ++i)
+	{
+		V3 v = v3f4(hullVerts[h.first + i]);
+		float d = dot(dir, v);
+		if (d > maxDist) { maxDist = d; result = v; }
+	}
+	return h.pos + h.q * result;
+}
+// The two convex shapes of one GJK/EPA instance.  A: capsule, cylinder, sphere (tubeA.a = centre), axis-aligned box, OBB or hull;
+// B: axis-aligned box, cylinder or hull.
+enum { SUP_CAPSULE = 0, SUP_CYLINDER = 1, SUP_SPHERE = 2, SUP_BOX = 3, SUP_OBB = 4, SUP_HULL = 5 };
+struct SupShapes { Capsule tubeA, tubeB; Box box, boxA; Obb obbA; Hull hullA, hullB; u32 kindA, kindB; const float4* hullVerts; };
+MI_DEV V3 supportA(const SupShapes& sh, V3 dir)
+{
+	switch (sh.kindA)
+	{
+		case SUP_CAPSULE: return capsuleSupport(sh.tubeA, dir);
+		case SUP_CYLINDER: return cylinderSupport(sh.tubeA, dir);
+		case SUP_SPHERE: return normalize(dir) * sh.tubeA.r + sh.tubeA.a; // collision_gjk.h:6-15
+		case SUP_BOX: return boxSupport(sh.boxA, dir);
+		case SUP_OBB: return obbSupport(sh.obbA, dir);
+		default: return hullSupport(sh.hullA, sh.hullVerts, dir);
+	}
+}
 MI_DEV SupportPoint supportPair(const SupShapes& sh, V3 dir)
 {
 	SupportPoint s;
-	s.a = sh.aIsCylinder ? cylinderSupport(sh.tubeA, dir) : capsuleSupport(sh.tubeA, dir);
-	s.b = sh.bIsCylinder ? cylinderSupport(sh.tubeB, -dir) : boxSupport(sh.box, -dir);
+	s.a = supportA(sh, dir);
+	s.b = (sh.kindB == SUP_BOX) ? boxSupport(sh.box, -dir) : ((sh.kindB == SUP_CYLINDER) ? cylinderSupport(sh.tubeB, -dir) : hullSupport(sh.hullB, sh.hullVerts, -dir));
 	s.mk = s.a - s.b;
 	return s;
 }
@@ -848,15 +877,41 @@ MI_DEV void capsuleBoxFinish(V3 point, V3 normal, float depth, const Capsule& c,
 		}
 	}
 }
-// Operands of one GJK/EPA instance by bucket key: 9 capsule-aabb, 10 capsule-obb, 14 cylinder-cylinder, 15 cylinder-aabb,
-// 16 cylinder-obb.  The obb variants work in the box's frame (:771-790, :1024-1043).
-MI_DEV void gjkOperands(u32 key, const ColliderRec& A, const ColliderRec& B, SupShapes& sh, Obb& o)
+// Keys (typeA * 6 + typeB) that go through GJK + EPA.
+MI_DEV bool gjkKey(u32 key) { return key == 5 || key == 9 || key == 10 || key == 11 || key == 14 || key == 15 || key == 16 || key == 17 || key == 23 || key == 29 || key == 35; }
+MI_DEV Hull asHull(const ColliderRec& c, const float4* __restrict__ hullInfo)
 {
-	sh.tubeA = asCapsule(A);
-	sh.aIsCylinder = key >= 14;
-	sh.bIsCylinder = key == 14;
-	sh.tubeB = sh.tubeA; sh.box.lo = v3s(0.f); sh.box.hi = v3s(0.f);
-	if (key == 14) { sh.tubeB = asCapsule(B); return; }
+	Hull h; h.q = q4f4(c.a); h.pos = v3(c.b.x, c.b.y, c.b.z);
+	u32 g = (u32)c.b.w;
+	h.first = __float_as_uint(hullInfo[2 * g].w); h.count = __float_as_uint(hullInfo[2 * g + 1].w);
+	return h;
+}
+// Operands of one GJK/EPA instance by bucket key: 9 capsule-aabb, 10 capsule-obb, 14 cylinder-cylinder, 15 cylinder-aabb,
+// 16 cylinder-obb (the obb variants work in the box's frame, :771-790, :1024-1043), and x-hull for x = 5 sphere, 11 capsule,
+// 17 cylinder, 23 aabb, 29 obb, 35 hull.
+MI_DEV void gjkOperands(u32 key, const ColliderRec& A, const ColliderRec& B, const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts, SupShapes& sh, Obb& o)
+{
+	sh.hullVerts = hullVerts;
+	sh.tubeA = asCapsule(A); sh.tubeB = sh.tubeA;
+	sh.box.lo = v3s(0.f); sh.box.hi = v3s(0.f); sh.boxA = sh.box;
+	sh.obbA.q = q4(0.f, 0.f, 0.f, 1.f); sh.obbA.c = v3s(0.f); sh.obbA.r = v3s(0.f);
+	sh.hullA.q = sh.obbA.q; sh.hullA.pos = v3s(0.f); sh.hullA.first = 0; sh.hullA.count = 0; sh.hullB = sh.hullA;
+	sh.kindA = (key >= 14) ? SUP_CYLINDER : SUP_CAPSULE; sh.kindB = SUP_BOX;
+	if (key % 6 == 5) // x vs hull
+	{
+		sh.kindB = SUP_HULL; sh.hullB = asHull(B, hullInfo);
+		switch (key / 6)
+		{
+			case 0: { Sphere s = asSphere(A); sh.kindA = SUP_SPHERE; sh.tubeA.a = s.c; sh.tubeA.b = s.c; sh.tubeA.r = s.r; } break;
+			case 1: sh.kindA = SUP_CAPSULE; break;
+			case 2: sh.kindA = SUP_CYLINDER; break;
+			case 3: sh.kindA = SUP_BOX; sh.boxA = asBox(A); break;
+			case 4: sh.kindA = SUP_OBB; sh.obbA = asObb(A); break;
+			default: sh.kindA = SUP_HULL; sh.hullA = asHull(A, hullInfo); break;
+		}
+		return;
+	}
+	if (key == 14) { sh.kindB = SUP_CYLINDER; sh.tubeB = asCapsule(B); return; }
 	if (key == 9 || key == 15) { sh.box = asBox(B); return; }
 	o = asObb(B);
 	sh.box.lo = o.c - o.r; sh.box.hi = o.c + o.r;
@@ -883,7 +938,7 @@ MI_DEV void writeManifold(ManifoldRec* __restrict__ out, u32 slot, const Man& m,
 enum { GROUP_CLOSED = 0, GROUP_BOX = 1 };
 
 // GROUP_CLOSED scans all valid slots and skips foreign buckets (its buckets are scattered over the key space);
-// GROUP_BOX covers the contiguous slot range of keys 22..28 (aabb-obb, obb-obb; keys 23..27 are hull pairs and never occur).
+// GROUP_BOX covers the contiguous slot range of keys 22..28 (aabb-obb, obb-obb; key 23, aabb-hull, is skipped: GJK + EPA).
 template <int GROUP>
 __global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
 	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds)
@@ -930,15 +985,17 @@ __global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(con
 // their empty manifold; hits append (slot, simplex) to the EPA work list so that phase 2 runs with dense waves — the
 // expanding polytope needs ~3.7 KB of private scratch per lane and 20 serial iterations, which must not idle behind misses.
 __global__ void __launch_bounds__(256) k_gjk(u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
-	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, u32* __restrict__ epaList, float4* __restrict__ gjkSimplex)
+	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, u32* __restrict__ epaList, float4* __restrict__ gjkSimplex,
+	const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts)
 {
-	u32 slot = counters[CTR_BUCKET_START + 9] + blockIdx.x * blockDim.x + threadIdx.x;
-	if (slot >= counters[CTR_BUCKET_START + 17]) return;
+	u32 slot = counters[CTR_BUCKET_START + 5] + blockIdx.x * blockDim.x + threadIdx.x; // keys 5..35; the closed-form and box keys in between are skipped
+	if (slot >= counters[CTR_BUCKET_START + 36]) return;
 	u32 key = keySorted[slot];
+	if (!gjkKey(key)) return;
 	u64 packed = pairSorted[slot];
 	ColliderRec A = colWorld[(u32)packed], B = colWorld[(u32)(packed >> 32)];
 	SupShapes sh; Obb o;
-	gjkOperands(key, A, B, sh, o);
+	gjkOperands(key, A, B, hullInfo, hullVerts, sh, o);
 	if (key == 14)
 	{
 		Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
@@ -965,7 +1022,8 @@ __global__ void __launch_bounds__(256) k_gjk(u32* __restrict__ counters, const u
 // Phase 2: EPA (one wave per hit, polytope in LDS) + face clipping (lane 0) for every GJK hit.  Waves stride over the work list.
 #define EPA_WAVES_PER_BLOCK 4
 __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) k_epa(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
-	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, const u32* __restrict__ epaList, const float4* __restrict__ gjkSimplex)
+	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, const u32* __restrict__ epaList, const float4* __restrict__ gjkSimplex,
+	const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts)
 {
 	__shared__ EpaWave shared[EPA_WAVES_PER_BLOCK];
 	u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -979,7 +1037,7 @@ __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) k_epa(const u32* __r
 		u64 packed = pairSorted[slot];
 		ColliderRec A = colWorld[(u32)packed], B = colWorld[(u32)(packed >> 32)];
 		SupShapes sh; Obb o;
-		gjkOperands(key, A, B, sh, o);
+		gjkOperands(key, A, B, hullInfo, hullVerts, sh, o);
 		const float4* S = gjkSimplex + (size_t)j * 9;
 		float f[36];
 		for (u32 i = 0; i < 9; ++i) { float4 v = S[i]; f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w; }
@@ -991,7 +1049,7 @@ __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) k_epa(const u32* __r
 		if (lane == 0)
 		{
 			Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
-			if (key == 14) { m.n = normal; m.count = 1; m.p[0] = make_float4(point.x, point.y, point.z, depth); } // :905-950
+			if (key == 14 || key % 6 == 5) { m.n = normal; m.count = 1; m.p[0] = make_float4(point.x, point.y, point.z, depth); } // :905-950; hull pairs
 			else capsuleBoxFinish(point, normal, depth, sh.tubeA, sh.box, m);
 			if (key == 10 || key == 16) // back to world space (:779-787, :1032-1040)
 			{
@@ -1016,9 +1074,9 @@ void launch_narrowphase(World& w, u32 numPairs)
 	csort_pairs_u64(w, w.pairKey.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p + numPairs, (u64*)w.pairsSorted.p, numPairs, 64);
 	hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p);
 	const u64* sortedPairs = (const u64*)w.pairsSorted.p;
-	hipLaunchKernelGGL(k_gjk, grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p);
+	hipLaunchKernelGGL(k_gjk, grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_CLOSED>), grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_BOX>), dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p);
 	u32 epaBlocks = std::min<u32>((numPairs + EPA_WAVES_PER_BLOCK - 1) / EPA_WAVES_PER_BLOCK, 256u * 4u); // 4 blocks of 4 waves (38.5 KB of LDS each) fit a CU
-	hipLaunchKernelGGL(k_epa, dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p);
+	hipLaunchKernelGGL(k_epa, dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p);
 }

@@ -96,6 +96,8 @@ struct World
 	struct HCollider { float shape[10]; float restitution, friction, density; u32 type, body; float spos[3], srot[4]; };
 	std::vector<HBody> bodies;
 	std::vector<HCollider> colliders;
+	struct HHull { std::vector<float> vertices; std::vector<u32> triangles; float aabbMin[3], aabbMax[3]; }; // bounding_hull_geometry (bounding_volumes.h:208-218)
+	std::vector<HHull> hulls;
 	JointSet joints[MI_JOINT_TYPES];
 	bool topologyDirty = true;   // bodies/colliders added since last upload
 	bool jointsDirty = true;
@@ -106,6 +108,7 @@ struct World
 	DevBuf<float4> pose, pose0, poseLerp, vel, bprops, force, cog, invIw;
 	DevBuf<ColliderRec> colLocal, colWorld;
 	DevBuf<float4> colStaticPose, aabbMin, aabbMax;
+	DevBuf<float4> hullVerts, hullInfo;   // all hull vertices (xyz); per geometry {aabbMin.xyz, firstVertex}, {aabbMax.xyz, vertexCount}
 	DevBuf<uint8_t> simMask;              // per body: 1 = simulated here (owned or ghost), 0 = lives on another GPU's slab
 	// broadphase
 	DevBuf<u32> hashKey, hashKeySorted, sortIdx, sortIdxSorted, cellStart, cellEnd, largeFlag, largeScan, largeList, pairCount, pairOffset;

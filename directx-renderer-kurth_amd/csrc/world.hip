@@ -102,12 +102,42 @@ static M3 minvert(const M3& m) // math.cpp:276-306
 	return mscaleH(inv, 1.f / det);
 }
 
-static MassProps colliderMassProps(const World::HCollider& c)
+static M3 maddH(const M3& a, const M3& b) { M3 r; const float* pa = &a.m00; const float* pb = &b.m00; float* pr = &r.m00; for (int i = 0; i < 9; ++i) pr[i] = pa[i] + pb[i]; return r; }
+static M3 msubH(const M3& a, const M3& b) { M3 r; const float* pa = &a.m00; const float* pb = &b.m00; float* pr = &r.m00; for (int i = 0; i < 9; ++i) pr[i] = pa[i] - pb[i]; return r; }
+static MassProps colliderMassProps(const World::HCollider& c, const World& w)
 {
 	MassProps r; r.inertia = mzero(); r.cog = v3s(0.f); r.mass = 0.f;
 	const float* s = c.shape;
 	switch (c.type)
 	{
+		case MI_HULL: // physics.cpp:1520-1580: signed tetrahedra (origin, face) with the covariance of the unit tetrahedron
+		{
+			Q4 rot = q4(s[0], s[1], s[2], s[3]); V3 pos = v3(s[4], s[5], s[6]);
+			const World::HHull& g = w.hulls[(u32)s[7]];
+			const float s60 = 1.f / 60.f, s120 = 1.f / 120.f;
+			M3 C; C.m00 = s60; C.m01 = s120; C.m02 = s120; C.m10 = s120; C.m11 = s60; C.m12 = s120; C.m20 = s120; C.m21 = s120; C.m22 = s60;
+			float totalMass = 0.f; M3 totalCov = mzero(); V3 totalCOG = v3s(0.f);
+			for (size_t f = 0; f + 2 < g.triangles.size(); f += 3)
+			{
+				const float* pa = &g.vertices[3 * g.triangles[f]]; const float* pb = &g.vertices[3 * g.triangles[f + 1]]; const float* pc = &g.vertices[3 * g.triangles[f + 2]];
+				V3 w1 = pos + rot * v3(pa[0], pa[1], pa[2]), w2 = pos + rot * v3(pb[0], pb[1], pb[2]), w3 = pos + rot * v3(pc[0], pc[1], pc[2]);
+				M3 A; A.m00 = w1.x; A.m01 = w2.x; A.m02 = w3.x; A.m10 = w1.y; A.m11 = w2.y; A.m12 = w3.y; A.m20 = w1.z; A.m21 = w2.z; A.m22 = w3.z;
+				float detA = A.m00 * (A.m11 * A.m22 - A.m21 * A.m12) - A.m01 * (A.m10 * A.m22 - A.m20 * A.m12) + A.m02 * (A.m10 * A.m21 - A.m20 * A.m11);
+				M3 cov = (mscaleH(A, detA) * C) * mtranspose(A);
+				float volume = 1.f / 6.f * detA;
+				V3 cg = (w1 + w2 + w3) * 0.25f;
+				totalMass += volume;
+				totalCov = maddH(totalCov, cov);
+				totalCOG += cg * volume;
+			}
+			totalCOG = totalCOG / totalMass;
+			V3 c0 = totalCOG * totalCOG.x, c1 = totalCOG * totalCOG.y, c2 = totalCOG * totalCOG.z; // outerProduct(cog, cog), math.cpp:778-795
+			M3 outer; outer.m00 = c0.x; outer.m10 = c0.y; outer.m20 = c0.z; outer.m01 = c1.x; outer.m11 = c1.y; outer.m21 = c1.z; outer.m02 = c2.x; outer.m12 = c2.y; outer.m22 = c2.z;
+			M3 Cp = msubH(totalCov, mscaleH(outer, totalMass));
+			r.cog = totalCOG;
+			r.mass = totalMass * c.density;
+			r.inertia = mscaleH(msubH(mscaleH(midentity(), Cp.m00 + Cp.m11 + Cp.m22), Cp), c.density);
+		} break;
 		case MI_SPHERE:
 		{
 			float radius = s[3];
@@ -196,7 +226,7 @@ static void recalculateProperties(World& w, World::HBody& rb) // rigid_body.cpp:
 	u32 n = (u32)rb.colliders.size();
 	if (!n) return;
 	std::vector<MassProps> props(n);
-	for (u32 i = 0; i < n; ++i) props[i] = colliderMassProps(w.colliders[rb.colliders[n - 1 - i]]); // newest first (scene.h:56-58)
+	for (u32 i = 0; i < n; ++i) props[i] = colliderMassProps(w.colliders[rb.colliders[n - 1 - i]], w); // newest first (scene.h:56-58)
 	M3 inertia = mzero(); V3 cog = v3s(0.f); float mass = 0.f;
 	for (u32 i = 0; i < n; ++i) { mass += props[i].mass; cog += props[i].cog * props[i].mass; }
 	rb.invMass = 1.f / mass;
@@ -272,6 +302,21 @@ void World::upload()
 		hc[i] = r;
 		hsp[2 * i] = make_float4(c.spos[0], c.spos[1], c.spos[2], 0.f);
 		hsp[2 * i + 1] = make_float4(c.srot[0], c.srot[1], c.srot[2], c.srot[3]);
+	}
+
+	std::vector<float4> hhv, hhi; // hull vertex pool + per-geometry info
+	for (const HHull& g : hulls)
+	{
+		u32 first = (u32)hhv.size(), count = (u32)(g.vertices.size() / 3);
+		for (u32 v = 0; v < count; ++v) hhv.push_back(make_float4(g.vertices[3 * v], g.vertices[3 * v + 1], g.vertices[3 * v + 2], 0.f));
+		hhi.push_back(make_float4(g.aabbMin[0], g.aabbMin[1], g.aabbMin[2], mi_u2f(first)));
+		hhi.push_back(make_float4(g.aabbMax[0], g.aabbMax[1], g.aabbMax[2], mi_u2f(count)));
+	}
+	hullVerts.ensure(std::max<size_t>(hhv.size(), 1), stream); hullInfo.ensure(std::max<size_t>(hhi.size(), 2), stream);
+	if (!hhv.empty())
+	{
+		MI_CHECK(hipMemcpyAsync(hullVerts.p, hhv.data(), sizeof(float4) * hhv.size(), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipMemcpyAsync(hullInfo.p, hhi.data(), sizeof(float4) * hhi.size(), hipMemcpyHostToDevice, stream));
 	}
 
 	nb = newNb; nc = newNc;
@@ -609,10 +654,11 @@ uint32_t mi_add_body(mi_world* world, int kinematic, float gravityFactor, float 
 
 static uint32_t addCollider(World* w, uint32_t body, uint32_t type, const float* shape, const mi_material* material, const float* pos, const float* rot)
 {
-	if (type > MI_OBB) { w->fail(MI_ERR_UNSUPPORTED, "collider type not supported by the HIP narrowphase (hull)"); return 0xFFFFFFFFu; }
+	if (type > MI_HULL) { w->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_collider: unknown collider type"); return 0xFFFFFFFFu; }
+	if (type == MI_HULL && (shape[7] < 0.f || (size_t)shape[7] >= w->hulls.size())) { w->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_collider: hull geometry index out of range (mi_add_hull_geometry first)"); return 0xFFFFFFFFu; }
 	if (body != MI_STATIC_BODY && body >= w->bodies.size()) { w->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_collider: body out of range"); return 0xFFFFFFFFu; }
 	World::HCollider c; memset(&c, 0, sizeof(c));
-	u32 n = (type == MI_SPHERE) ? 4 : ((type == MI_CAPSULE || type == MI_CYLINDER) ? 7 : (type == MI_AABB ? 6 : 10));
+	u32 n = (type == MI_SPHERE) ? 4 : ((type == MI_CAPSULE || type == MI_CYLINDER) ? 7 : (type == MI_AABB ? 6 : (type == MI_HULL ? 8 : 10)));
 	memcpy(c.shape, shape, n * sizeof(float));
 	c.restitution = material->restitution; c.friction = material->friction; c.density = material->density;
 	c.type = type; c.body = body;
@@ -629,6 +675,21 @@ static uint32_t addCollider(World* w, uint32_t body, uint32_t type, const float*
 	w->topologyDirty = true;
 	return id;
 }
+uint32_t mi_add_hull_geometry(mi_world* world, const float* vertices3, uint32_t numVertices, const uint32_t* triangles3, uint32_t numTriangles)
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	if (!vertices3 || !triangles3 || numVertices < 4 || numTriangles < 4) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_hull_geometry: a convex hull needs at least 4 vertices and 4 triangles"); return 0xFFFFFFFFu; }
+	World::HHull g;
+	g.vertices.assign(vertices3, vertices3 + 3 * (size_t)numVertices);
+	g.triangles.assign(triangles3, triangles3 + 3 * (size_t)numTriangles);
+	for (uint32_t t = 0; t < 3 * numTriangles; ++t) if (triangles3[t] >= numVertices) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_hull_geometry: triangle index out of range"); return 0xFFFFFFFFu; }
+	for (int k = 0; k < 3; ++k) { g.aabbMin[k] = MI_FLT_MAX; g.aabbMax[k] = -MI_FLT_MAX; }
+	for (uint32_t v = 0; v < numVertices; ++v) for (int k = 0; k < 3; ++k) { g.aabbMin[k] = fminf(g.aabbMin[k], vertices3[3 * v + k]); g.aabbMax[k] = fmaxf(g.aabbMax[k], vertices3[3 * v + k]); }
+	W->hulls.push_back(g);
+	W->topologyDirty = true;
+	return (uint32_t)W->hulls.size() - 1;
+}
+
 uint32_t mi_add_collider(mi_world* world, uint32_t body, uint32_t type, const float* shape, const mi_material* material)
 {
 	CHECK_WORLD(0xFFFFFFFFu);

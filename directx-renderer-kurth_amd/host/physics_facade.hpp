@@ -41,6 +41,7 @@ namespace mi
 	struct bounding_cylinder { vec3 positionA, positionB; float radius; };
 	struct bounding_box { vec3 minCorner, maxCorner; static bounding_box fromCenterRadius(vec3 c, vec3 r) { return { { c.x - r.x, c.y - r.y, c.z - r.z }, { c.x + r.x, c.y + r.y, c.z + r.z } }; } };
 	struct bounding_oriented_box { quat rotation; vec3 center, radius; };
+	struct bounding_hull { quat rotation; vec3 position; uint32_t geometryIndex; }; // geometryIndex from game_scene::allocateBoundingHullGeometry
 
 	struct physics_material { float restitution, friction, density; }; // physics.h:40-47 without the sound tag
 
@@ -55,6 +56,7 @@ namespace mi
 		static collider_component asCylinder(bounding_cylinder s, physics_material m) { collider_component c; c.type = MI_COLLIDER_CYLINDER; c.set({ s.positionA.x, s.positionA.y, s.positionA.z, s.positionB.x, s.positionB.y, s.positionB.z, s.radius }); c.material = m; return c; }
 		static collider_component asAABB(bounding_box b, physics_material m) { collider_component c; c.type = MI_COLLIDER_AABB; c.set({ b.minCorner.x, b.minCorner.y, b.minCorner.z, b.maxCorner.x, b.maxCorner.y, b.maxCorner.z }); c.material = m; return c; }
 		static collider_component asOBB(bounding_oriented_box b, physics_material m) { collider_component c; c.type = MI_COLLIDER_OBB; c.set({ b.rotation.x, b.rotation.y, b.rotation.z, b.rotation.w, b.center.x, b.center.y, b.center.z, b.radius.x, b.radius.y, b.radius.z }); c.material = m; return c; }
+		static collider_component asHull(bounding_hull h, physics_material m) { collider_component c; c.type = MI_COLLIDER_HULL; c.set({ h.rotation.x, h.rotation.y, h.rotation.z, h.rotation.w, h.position.x, h.position.y, h.position.z, (float)h.geometryIndex }); c.material = m; return c; }
 	private:
 		void set(std::initializer_list<float> v) { int i = 0; for (float f : v) shape[i++] = f; }
 	};
@@ -146,6 +148,13 @@ namespace mi
 		}
 		~game_scene() { if (world) mi_world_destroy(world); }
 		game_scene(const game_scene&) = delete; game_scene& operator=(const game_scene&) = delete;
+
+		// allocateBoundingHullGeometry (physics.h:207) from the mesh on: vertices + outward-facing triangles instead of a model file
+		uint32_t allocateBoundingHullGeometry(const std::vector<vec3>& vertices, const std::vector<uint32_t>& triangles)
+		{
+			static_assert(sizeof(vec3) == 12, "vec3 is three floats");
+			return checkId(mi_add_hull_geometry(world, &vertices[0].x, (uint32_t)vertices.size(), triangles.data(), (uint32_t)(triangles.size() / 3)), "allocateBoundingHullGeometry");
+		}
 
 		scene_entity createEntity(const char* /*name*/ = nullptr) { entities.emplace_back(); return scene_entity{ this, (uint32_t)entities.size() - 1 }; }
 

@@ -10,7 +10,7 @@ listed in BASELINE.md.  The humanoid ragdoll geometry restates src/physics/ragdo
 import math
 import numpy as np
 
-SPHERE, CAPSULE, CYLINDER, AABB, OBB = 0, 1, 2, 3, 4
+SPHERE, CAPSULE, CYLINDER, AABB, OBB, HULL = 0, 1, 2, 3, 4, 5
 STATIC = 0xFFFFFFFF
 _M64 = (1 << 64) - 1
 
@@ -52,6 +52,7 @@ class Scene:
         self.bodies = []      # (pos3, rot4, kinematic, gravityFactor, linDamp, angDamp)
         self.colliders = []   # (body or STATIC, type, shape[<=10], material3, static_pos3, static_rot4)
         self.joints = []      # ("hinge"|"cone_twist"|..., a, b, args...)
+        self.hulls = []       # convex hull geometries: (vertices [n,3], triangles [m,3]); HULL colliders refer to them by index
 
     def add_body(self, pos, rot=(0, 0, 0, 1), kinematic=False, gravity_factor=1.0, linear_damping=0.4, angular_damping=0.4):
         self.bodies.append((tuple(float(x) for x in pos), tuple(float(x) for x in rot), kinematic, gravity_factor, linear_damping, angular_damping))
@@ -61,6 +62,10 @@ class Scene:
         self.colliders.append((body, ctype, tuple(float(x) for x in shape), tuple(material), tuple(pos), tuple(rot)))
         return len(self.colliders) - 1
 
+    def add_hull_geometry(self, vertices, triangles):
+        self.hulls.append((np.asarray(vertices, np.float32).reshape(-1, 3), np.asarray(triangles, np.uint32).reshape(-1, 3)))
+        return len(self.hulls) - 1
+
     def add_joint(self, kind, a, b, *args):
         self.joints.append((kind, a, b) + args)
 
@@ -69,6 +74,8 @@ class Scene:
         return len(self.bodies)
 
     def instantiate(self, world):
+        for v, t in self.hulls:
+            world.add_hull_geometry(v, t)
         for pos, rot, kin, g, ld, ad in self.bodies:
             world.add_body(pos, rot, kinematic=kin, gravity_factor=g, linear_damping=ld, angular_damping=ad)
         for body, ctype, shape, mat, pos, rot in self.colliders:
@@ -183,6 +190,65 @@ def all_shapes(n=600, seed=90210377, column_height=6, pitch=1.6, layer=1.5):
         else:
             he = (rng.between(0.3, 0.8), rng.between(0.3, 0.8), rng.between(0.3, 0.8))
             s.add_collider(b, OBB, (0, 0, 0, 1, 0, 0, 0) + he, DEFAULT_MATERIAL)
+    return s
+
+
+# ---- convex hull geometries (outward-facing triangles) -------------------------------------------------------
+def hull_box(hx, hy, hz):
+    v = [(-hx, -hy, -hz), (hx, -hy, -hz), (hx, hy, -hz), (-hx, hy, -hz), (-hx, -hy, hz), (hx, -hy, hz), (hx, hy, hz), (-hx, hy, hz)]
+    t = [(0, 2, 1), (0, 3, 2), (4, 5, 6), (4, 6, 7), (0, 1, 5), (0, 5, 4), (2, 3, 7), (2, 7, 6), (1, 2, 6), (1, 6, 5), (0, 4, 7), (0, 7, 3)]
+    return v, t
+
+
+def hull_octahedron(r):
+    v = [(r, 0, 0), (-r, 0, 0), (0, r, 0), (0, -r, 0), (0, 0, r), (0, 0, -r)]
+    t = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    return v, t
+
+
+def hull_icosahedron(r):
+    p = (1.0 + math.sqrt(5.0)) / 2.0
+    s = r / math.sqrt(1.0 + p * p)
+    v = [(-1, p, 0), (1, p, 0), (-1, -p, 0), (1, -p, 0), (0, -1, p), (0, 1, p), (0, -1, -p), (0, 1, -p), (p, 0, -1), (p, 0, 1), (-p, 0, -1), (-p, 0, 1)]
+    v = [(a * s, b * s, c * s) for a, b, c in v]
+    t = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    return v, t
+
+
+def all_shapes_hull(n=490, seed=55120931, column_height=7, pitch=1.7, layer=1.6):
+    """all_shapes plus convex hulls (box, octahedron, icosahedron geometries): every one of the 21 collider type pairs of
+    collision_narrow.cpp:2473-2570 occurs."""
+    rng = XorShift64(seed)
+    s = Scene("all_shapes_hull_%d" % n)
+    _ground(s, 30.0)
+    geoms = [s.add_hull_geometry(*hull_box(0.5, 0.35, 0.45)), s.add_hull_geometry(*hull_octahedron(0.6)), s.add_hull_geometry(*hull_icosahedron(0.55))]
+    ncol = (n + column_height - 1) // column_height
+    side = int(math.ceil(math.sqrt(ncol)))
+    for i in range(n):
+        c, k = divmod(i, column_height)
+        cx = (c % side - 0.5 * (side - 1)) * pitch
+        cz = (c // side - 0.5 * (side - 1)) * pitch
+        pos = (cx + rng.between(-0.1, 0.1), 1.0 + layer * k + rng.between(0, 0.05), cz + rng.between(-0.1, 0.1))
+        rot = rng.unit_quat()
+        if i % 5 == 0:
+            rot = (0.0, 0.0, 0.0, 1.0)
+        b = s.add_body(pos, rot)
+        kind = i % 6
+        if kind == 0:
+            s.add_collider(b, SPHERE, (0, 0, 0, rng.between(0.3, 0.6)), DEFAULT_MATERIAL)
+        elif kind == 1:
+            s.add_collider(b, CAPSULE, (-0.5, 0, 0, 0.5, 0, 0, 0.25), DEFAULT_MATERIAL)
+        elif kind == 2:
+            s.add_collider(b, CYLINDER, (-0.5, 0, 0, 0.5, 0, 0, rng.between(0.25, 0.5)), DEFAULT_MATERIAL)
+        elif kind == 3:
+            he = (rng.between(0.3, 0.7), rng.between(0.3, 0.7), rng.between(0.3, 0.7))
+            s.add_collider(b, AABB, (-he[0], -he[1], -he[2]) + he, DEFAULT_MATERIAL)
+        elif kind == 4:
+            he = (rng.between(0.3, 0.8), rng.between(0.3, 0.8), rng.between(0.3, 0.8))
+            s.add_collider(b, OBB, (0, 0, 0, 1, 0, 0, 0) + he, DEFAULT_MATERIAL)
+        else:
+            s.add_collider(b, HULL, (0, 0, 0, 1, 0, 0, 0, float(geoms[(i // 6) % 3])), DEFAULT_MATERIAL)
     return s
 
 
@@ -318,4 +384,6 @@ def by_name(name):
         return c3_mixed(20000)
     if name == "shapes":
         return all_shapes()
+    if name == "shapes_hull":
+        return all_shapes_hull()
     raise KeyError(name)

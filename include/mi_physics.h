@@ -75,9 +75,14 @@ const char* mi_last_error(mi_world* w);                               /* w may b
 /* entity.addComponent<rigid_body_component>(kinematic, gravityFactor, linearDamping=.4, angularDamping=.4) on an entity with
  * transform {pos, rot}: rigid_body.h:21, rigid_body.cpp:6-27, scene.h:69-84.  Returns the body index (= add order). */
 uint32_t mi_add_body(mi_world* w, int kinematic, float gravityFactor, float linearDamping, float angularDamping, const float pos[3], const float rot[4]);
-/* entity.addComponent<collider_component>(collider_component::as{Sphere,Capsule,Cylinder,AABB,OBB}(shape, material)): physics.h:110-157,
+/* Convex hull geometry shared by hull colliders: replaces allocateBoundingHullGeometry(meshFilepath) (physics.h:207, physics.cpp:58-84)
+ * from the mesh on — loading a model file belongs to the asset pipeline — i.e. bounding_hull_geometry::fromMesh(vertices, triangles)
+ * (bounding_volumes.cpp:1394-1452).  Triangles face outwards.  Returns the geometry index (INVALID = 0xFFFFFFFF). */
+uint32_t mi_add_hull_geometry(mi_world* w, const float* vertices3, uint32_t numVertices, const uint32_t* triangles3, uint32_t numTriangles);
+/* entity.addComponent<collider_component>(collider_component::as{Sphere,Capsule,Cylinder,AABB,OBB,Hull}(shape, material)): physics.h:110-157,
  * scene.h:38-63 (recomputes the body's mass properties, rigid_body.cpp:29-81).  shape = up to 10 floats in the parent's local space:
- * sphere c3,r | capsule/cylinder A3,B3,r | aabb min3,max3 | obb quat4,center3,radius3.  Returns the collider index. */
+ * sphere c3,r | capsule/cylinder A3,B3,r | aabb min3,max3 | obb quat4,center3,radius3 | hull quat4,position3,geometry index (as a float
+ * value).  Returns the collider index. */
 uint32_t mi_add_collider(mi_world* w, uint32_t body, uint32_t type, const float* shape, const mi_material* material);
 /* Collider on an entity without a rigid body (static_collider, physics.cpp:667-671); {pos, rot} is that entity's transform. */
 uint32_t mi_add_static_collider(mi_world* w, uint32_t type, const float* shape, const mi_material* material, const float pos[3], const float rot[4]);

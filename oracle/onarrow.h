@@ -272,6 +272,24 @@ struct obb_support_fn
 	}
 };
 
+// collision_gjk.h:77-100
+struct hull_support_fn
+{
+	bounding_hull h;
+	vec3 operator()(vec3 dir) const
+	{
+		dir = conjugate(h.rotation) * dir;
+		vec3 result(0.f);
+		float maxDist = -FLT_MAX;
+		for (const vec3& v : (*hullGeometryTable())[h.geometryIndex].vertices)
+		{
+			float d = dot(dir, v);
+			if (d > maxDist) { maxDist = d; result = v; }
+		}
+		return h.position + h.rotation * result;
+	}
+};
+
 struct gjk_support_point
 {
 	vec3 shapeAPoint, shapeBPoint, minkowski;
@@ -1049,7 +1067,24 @@ static inline bool intersection(const bounding_box& a, const bounding_oriented_b
 	return intersection(bounding_oriented_box{ quat(0.f, 0.f, 0.f, 1.f), a.getCenter(), a.getRadius() }, b, outContact);
 }
 
-// Dispatch on (typeA <= typeB), the 15 in-scope pairs of collision_narrow.cpp:2473-2570.  Returns false for hull pairs.
+// Every (*, hull) pair: GJK + EPA, single contact, EPA status ignored — collision_narrow.cpp:496-520 (sphere), 792-818 (capsule),
+// 1045-1071 (cylinder), 1150-1176 (aabb), 1529-1556 (obb), 1559-1584 (hull).
+template <typename Support>
+static inline bool supportVsHull(const Support& a, const bounding_hull& h, contact_manifold& outContact)
+{
+	hull_support_fn hullSupport{ h };
+	gjk_simplex gjkSimplex;
+	if (!gjkIntersectionTest(a, hullSupport, gjkSimplex)) { return false; }
+	epa_result epa;
+	epaCollisionInfo(gjkSimplex, a, hullSupport, epa);
+	outContact.collisionNormal = epa.normal;
+	outContact.numContacts = 1;
+	outContact.contacts[0].penetrationDepth = epa.penetrationDepth;
+	outContact.contacts[0].point = epa.point;
+	return true;
+}
+
+// Dispatch on (typeA <= typeB), the 21 pairs of collision_narrow.cpp:2473-2570.
 static inline bool intersectColliders(const collider_union& A, const collider_union& B, contact_manifold& m)
 {
 	switch (A.type)
@@ -1062,6 +1097,7 @@ static inline bool intersectColliders(const collider_union& A, const collider_un
 				case collider_type_cylinder: return intersection(A.sphere(), B.cylinder(), m);
 				case collider_type_aabb: return intersection(A.sphere(), B.aabb(), m);
 				case collider_type_obb: return intersection(A.sphere(), B.obb(), m);
+				case collider_type_hull: return supportVsHull(sphere_support_fn{ A.sphere() }, B.hull(), m);
 			}
 			break;
 		case collider_type_capsule:
@@ -1071,6 +1107,7 @@ static inline bool intersectColliders(const collider_union& A, const collider_un
 				case collider_type_cylinder: return intersection(A.capsule(), B.cylinder(), m);
 				case collider_type_aabb: return intersection(A.capsule(), B.aabb(), m);
 				case collider_type_obb: return intersection(A.capsule(), B.obb(), m);
+				case collider_type_hull: return supportVsHull(capsule_support_fn{ A.capsule() }, B.hull(), m);
 			}
 			break;
 		case collider_type_cylinder:
@@ -1079,6 +1116,7 @@ static inline bool intersectColliders(const collider_union& A, const collider_un
 				case collider_type_cylinder: return intersection(A.cylinder(), B.cylinder(), m);
 				case collider_type_aabb: return intersection(A.cylinder(), B.aabb(), m);
 				case collider_type_obb: return intersection(A.cylinder(), B.obb(), m);
+				case collider_type_hull: return supportVsHull(cylinder_support_fn{ A.cylinder() }, B.hull(), m);
 			}
 			break;
 		case collider_type_aabb:
@@ -1086,10 +1124,15 @@ static inline bool intersectColliders(const collider_union& A, const collider_un
 			{
 				case collider_type_aabb: return intersection(A.aabb(), B.aabb(), m);
 				case collider_type_obb: return intersection(A.aabb(), B.obb(), m);
+				case collider_type_hull: return supportVsHull(aabb_support_fn{ A.aabb() }, B.hull(), m);
 			}
 			break;
 		case collider_type_obb:
 			if (B.type == collider_type_obb) return intersection(A.obb(), B.obb(), m);
+			if (B.type == collider_type_hull) return supportVsHull(obb_support_fn{ A.obb() }, B.hull(), m);
+			break;
+		case collider_type_hull:
+			if (B.type == collider_type_hull) return supportVsHull(hull_support_fn{ A.hull() }, B.hull(), m);
 			break;
 	}
 	return false;

@@ -59,7 +59,7 @@ def _lib(avx2=False):
                      "orc_add_fixed_constraint_global", "orc_add_hinge_constraint_global", "orc_add_cone_twist_constraint_global",
                      "orc_add_slider_constraint_global", "orc_num_bodies", "orc_num_colliders", "orc_num_pairs", "orc_num_contacts",
                      "orc_num_collisions", "orc_sorting_axis_used", "orc_sorting_axis_next", "orc_num_contact_slots",
-                     "orc_narrowphase_ordered", "orc_schedule", "orc_read_slot_counts"):
+                     "orc_narrowphase_ordered", "orc_schedule", "orc_read_slot_counts", "orc_add_hull_geometry"):
             getattr(lib, name).restype = C.c_uint32
         _libs[key] = lib
     return _libs[key]
@@ -88,6 +88,15 @@ class OracleWorld:
     # ---- add API (reference physics.h:110-157, 209-235; rigid_body.h:21) -------------------------------
     def add_body(self, pos, rot=(0, 0, 0, 1), kinematic=False, gravity_factor=1.0, linear_damping=0.4, angular_damping=0.4):
         return self.lib.orc_add_body(self.w, int(kinematic), C.c_float(gravity_factor), C.c_float(linear_damping), C.c_float(angular_damping), _f(pos), _f(rot))
+
+    def add_hull_geometry(self, vertices, triangles):
+        """bounding_hull_geometry::fromMesh: convex vertex set + triangle list; returns the geometry index used by HULL colliders."""
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3); t = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        return self.lib.orc_add_hull_geometry(self.w, _f(v), C.c_uint32(len(v)), t.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(len(t)))
+
+    def use_hull_geometries(self):
+        """Stage-level functions (narrowphase_ordered) read hull vertices from this world's geometry table from now on."""
+        self.lib.orc_use_hull_geometries(self.w)
 
     def add_collider(self, body, ctype, shape, material):
         s = np.zeros(10, np.float32); s[:len(shape)] = shape

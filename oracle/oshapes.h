@@ -2,6 +2,7 @@
 // Shapes, AABB transforms and closest-point routines restated from the reference's
 // src/physics/bounding_volumes.{h,cpp}; collider record from src/physics/physics.h:40-171.
 #pragma once
+#include <vector>
 #include "omath.h"
 
 namespace orc {
@@ -173,8 +174,22 @@ static inline float closestPoint_SegmentSegment(const line_segment& l1, const li
 	return squaredLength(c1 - c2);
 }
 
+// bounding_volumes.h:196-231.  Convex hull: shared geometry (vertices + triangles; edges are not used on the rigid-body path) and a
+// placed instance.  The reference keeps the geometries in a global table (physics.cpp:47-84) and a pointer in the world-space
+// collider; here the table belongs to the world and hulls carry the index.
+struct bounding_hull_face { u32 a, b, c; };
+struct bounding_hull_geometry
+{
+	std::vector<vec3> vertices;
+	std::vector<bounding_hull_face> faces;
+	bounding_box aabb;
+};
+struct bounding_hull { quat rotation; vec3 position; u32 geometryIndex; };
+// the geometry table the narrowphase reads hull vertices from (set by the world around its narrowphase calls)
+inline const std::vector<bounding_hull_geometry>*& hullGeometryTable() { static const std::vector<bounding_hull_geometry>* t = nullptr; return t; }
+
 // physics.h:40-106.  The reference's collider_union is a 64-byte tagged union with u16 indices; we widen
-// objectIndex to u32 (SURVEY finding 1) and drop the hull arm (out of scope, §8 a19).
+// objectIndex to u32 (SURVEY finding 1).
 enum collider_type : u32
 {
 	collider_type_sphere, collider_type_capsule, collider_type_cylinder, collider_type_aabb, collider_type_obb, collider_type_hull,
@@ -188,7 +203,8 @@ struct physics_material { float restitution, friction, density; };
 
 struct collider_union
 {
-	// Shape payload: 10 floats, interpreted per type (sphere: c,r | capsule/cylinder: A,B,r | aabb: min,max | obb: q,c,r).
+	// Shape payload: 10 floats, interpreted per type (sphere: c,r | capsule/cylinder: A,B,r | aabb: min,max | obb: q,c,r |
+	// hull: q, position, geometry index as a float value).
 	float shape[10];
 	physics_material material;
 	u32 type;
@@ -199,6 +215,8 @@ struct collider_union
 	bounding_capsule capsule() const { return bounding_capsule{ vec3(shape[0], shape[1], shape[2]), vec3(shape[3], shape[4], shape[5]), shape[6] }; }
 	bounding_cylinder cylinder() const { return bounding_cylinder{ vec3(shape[0], shape[1], shape[2]), vec3(shape[3], shape[4], shape[5]), shape[6] }; }
 	bounding_box aabb() const { return bounding_box{ vec3(shape[0], shape[1], shape[2]), vec3(shape[3], shape[4], shape[5]) }; }
+	bounding_hull hull() const { return bounding_hull{ quat(shape[0], shape[1], shape[2], shape[3]), vec3(shape[4], shape[5], shape[6]), (u32)shape[7] }; }
+	void set(const bounding_hull& h) { shape[0] = h.rotation.x; shape[1] = h.rotation.y; shape[2] = h.rotation.z; shape[3] = h.rotation.w; shape[4] = h.position.x; shape[5] = h.position.y; shape[6] = h.position.z; shape[7] = (float)h.geometryIndex; shape[8] = shape[9] = 0.f; }
 	bounding_oriented_box obb() const { return bounding_oriented_box{ quat(shape[0], shape[1], shape[2], shape[3]), vec3(shape[4], shape[5], shape[6]), vec3(shape[7], shape[8], shape[9]) }; }
 	void set(const bounding_sphere& s) { shape[0] = s.center.x; shape[1] = s.center.y; shape[2] = s.center.z; shape[3] = s.radius; for (int i = 4; i < 10; ++i) shape[i] = 0.f; }
 	void set(const bounding_capsule& c) { shape[0] = c.positionA.x; shape[1] = c.positionA.y; shape[2] = c.positionA.z; shape[3] = c.positionB.x; shape[4] = c.positionB.y; shape[5] = c.positionB.z; shape[6] = c.radius; shape[7] = shape[8] = shape[9] = 0.f; }

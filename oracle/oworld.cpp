@@ -51,6 +51,7 @@ struct world
 {
 	std::vector<body> bodies;
 	std::vector<collider> colliders;
+	std::vector<bounding_hull_geometry> hullGeometries; // boundingHullGeometries (physics.cpp:47), per world instead of global
 
 	std::vector<distance_constraint> distanceConstraints; std::vector<constraint_body_pair> distancePairs;
 	std::vector<ball_constraint> ballConstraints; std::vector<constraint_body_pair> ballPairs;
@@ -94,11 +95,56 @@ struct world
 // ---------------------------------------------------------------------------------------------------
 struct physics_properties { mat3 inertia; vec3 cog; float mass; };
 
-static physics_properties calculatePhysicsProperties(const collider_union& c)
+// core/math.cpp:443-448
+static float determinant3(const mat3& m)
+{
+	return m.m00 * (m.m11 * m.m22 - m.m21 * m.m12)
+		- m.m01 * (m.m10 * m.m22 - m.m20 * m.m12)
+		+ m.m02 * (m.m10 * m.m21 - m.m20 * m.m11);
+}
+
+static physics_properties calculatePhysicsProperties(const collider_union& c, const std::vector<bounding_hull_geometry>& hullGeometries)
 {
 	physics_properties result;
 	switch (c.type)
 	{
+		case collider_type_hull: // physics.cpp:1520-1580 (http://number-none.com/blow/inertia/)
+		{
+			bounding_hull hull = c.hull();
+			const bounding_hull_geometry& geom = hullGeometries[hull.geometryIndex];
+			const float s60 = 1.f / 60.f, s120 = 1.f / 120.f;
+			mat3 Ccanonical; // covariance of the unit tetrahedron
+			Ccanonical.m00 = s60; Ccanonical.m01 = s120; Ccanonical.m02 = s120;
+			Ccanonical.m10 = s120; Ccanonical.m11 = s60; Ccanonical.m12 = s120;
+			Ccanonical.m20 = s120; Ccanonical.m21 = s120; Ccanonical.m22 = s60;
+			float totalMass = 0.f;
+			mat3 totalCovariance = mat3::zero();
+			vec3 totalCOG(0.f);
+			for (const bounding_hull_face& face : geom.faces)
+			{
+				vec3 w1 = hull.position + hull.rotation * geom.vertices[face.a];
+				vec3 w2 = hull.position + hull.rotation * geom.vertices[face.b];
+				vec3 w3 = hull.position + hull.rotation * geom.vertices[face.c];
+				mat3 A; // columns w1, w2, w3
+				A.m00 = w1.x; A.m01 = w2.x; A.m02 = w3.x;
+				A.m10 = w1.y; A.m11 = w2.y; A.m12 = w3.y;
+				A.m20 = w1.z; A.m21 = w2.z; A.m22 = w3.z;
+				float detA = determinant3(A);
+				mat3 covariance = ((A * detA) * Ccanonical) * transpose(A);
+				float volume = 1.f / 6.f * detA;
+				float mass = volume;
+				vec3 cog = (w1 + w2 + w3) * 0.25f;
+				totalMass += mass;
+				totalCovariance = totalCovariance + covariance;
+				totalCOG += cog * mass;
+			}
+			totalCOG /= totalMass;
+			mat3 CprimeTotal = totalCovariance - outerProduct(totalCOG, totalCOG) * totalMass;
+			result.cog = totalCOG;
+			result.mass = totalMass * c.material.density;
+			result.inertia = mat3::identity() * (CprimeTotal.m00 + CprimeTotal.m11 + CprimeTotal.m22) - CprimeTotal;
+			result.inertia = result.inertia * c.material.density;
+		} break;
 		case collider_type_sphere:
 		{
 			bounding_sphere s = c.sphere();
@@ -189,7 +235,7 @@ static void recalculateProperties(world& w, body& rb)
 	std::vector<physics_properties> properties(numColliders);
 	for (u32 i = 0; i < numColliders; ++i) // newest first, like the reference's intrusive list
 	{
-		properties[i] = calculatePhysicsProperties(w.colliders[rb.colliders[numColliders - 1 - i]].local);
+		properties[i] = calculatePhysicsProperties(w.colliders[rb.colliders[numColliders - 1 - i]].local, w.hullGeometries);
 	}
 	mat3 inertia = mat3::zero();
 	vec3 cog(0.f);
@@ -267,6 +313,15 @@ static void getWorldSpaceColliders(world& w)
 				bounding_oriented_box o = c.local.obb();
 				bb = o.transformToAABB(transform.rotation, transform.position);
 				col.set(o.transformToOBB(transform.rotation, transform.position));
+			} break;
+			case collider_type_hull: // physics.cpp:742-753
+			{
+				bounding_hull h = c.local.hull();
+				const bounding_hull_geometry& geometry = w.hullGeometries[h.geometryIndex];
+				quat rotation = transform.rotation * h.rotation;
+				vec3 position = transform.rotation * h.position + transform.position;
+				bb = geometry.aabb.transformToAABB(rotation, position);
+				col.set(bounding_hull{ rotation, position, h.geometryIndex });
 			} break;
 			default: break;
 		}
@@ -489,6 +544,7 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 
 	getWorldSpaceColliders(w);
 	broadphase(w);
+	hullGeometryTable() = &w.hullGeometries;
 	if (w.usePairOverride) { narrowphaseOverride(w); }
 	else { narrowphasePairs(w, w.broadphasePairs.data(), (u32)w.broadphasePairs.size()); }
 
@@ -654,6 +710,20 @@ static u32 addColliderCommon(world* w, u32 parent, u32 type, const float* shape,
 	}
 	return id;
 }
+// bounding_hull_geometry::fromMesh (bounding_volumes.cpp:1394-1442) without the edge table (unused on this path);
+// replaces allocateBoundingHullGeometry(meshFilepath) (physics.cpp:58-84), whose mesh loading belongs to the asset pipeline.
+u32 orc_add_hull_geometry(world* w, const float* vertices3, u32 numVertices, const u32* triangles3, u32 numTriangles)
+{
+	bounding_hull_geometry g;
+	g.aabb = bounding_box::negativeInfinity();
+	for (u32 i = 0; i < numVertices; ++i) { vec3 v(vertices3[3 * i], vertices3[3 * i + 1], vertices3[3 * i + 2]); g.vertices.push_back(v); g.aabb.grow(v); }
+	for (u32 i = 0; i < numTriangles; ++i) g.faces.push_back(bounding_hull_face{ triangles3[3 * i], triangles3[3 * i + 1], triangles3[3 * i + 2] });
+	w->hullGeometries.push_back(g);
+	return (u32)w->hullGeometries.size() - 1;
+}
+// makes this world's hull geometries the table the stage-level entry points (orc_narrowphase_ordered) read
+void orc_use_hull_geometries(world* w) { hullGeometryTable() = &w->hullGeometries; }
+
 u32 orc_add_collider(world* w, u32 bodyId, u32 type, const float* shape, const float* material) { return addColliderCommon(w, bodyId, type, shape, material, 0, 0); }
 u32 orc_add_static_collider(world* w, u32 type, const float* shape, const float* material, const float* pos, const float* rot) { return addColliderCommon(w, STATIC_BODY, type, shape, material, pos, rot); }
 

@@ -7,6 +7,7 @@ Fixtures (numpy .npz, loadable with allow_pickle=False):
   narrow_pairs.npz   10 in-scope collider type pairs x 48 seeded poses (incl. degenerate ones): scene description, world-space
                      colliders/AABBs, broadphase pair set and per-pair contacts as produced by one oracle step.
   narrow_pairs_cylinder.npz  the same for the 5 type pairs that involve a cylinder.
+  narrow_pairs_hull.npz      the same for the 6 type pairs that involve a convex hull (box, octahedron, icosahedron geometries).
   scheduler.npz      body-pair lists -> exact 8-lane slot tables of the greedy batch scheduler (constraints.cpp:51-184).
   c1_trajectory.npz  config 1 (64 OBBs on the ground): transforms + velocities after 1, 60, 120, 240 steps, scalar and 8-lane solver.
   ragdoll_trajectory.npz  one humanoid ragdoll dropped on the ground at 60 Hz (learned_locomotion.cpp:440-446,469-474): 1, 30, 120 steps.
@@ -25,8 +26,16 @@ sys.path.insert(0, ROOT)
 from directx_renderer_kurth_amd import scenes  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
-SPHERE, CAPSULE, CYLINDER, AABB, OBB = 0, 1, 2, 3, 4
+SPHERE, CAPSULE, CYLINDER, AABB, OBB, HULL = 0, 1, 2, 3, 4, 5
 MAT = (0.1, 0.5, 1.0)
+
+
+def hulls_to_arrays(s):
+    """Hull geometries of a scene as flat arrays: vertices, triangles, and the (first, count) ranges of both per geometry."""
+    v = np.concatenate([h[0] for h in s.hulls]) if s.hulls else np.zeros((0, 3), np.float32)
+    t = np.concatenate([h[1] for h in s.hulls]) if s.hulls else np.zeros((0, 3), np.uint32)
+    r = np.array([[sum(len(g[0]) for g in s.hulls[:i]), len(h[0]), sum(len(g[1]) for g in s.hulls[:i]), len(h[1])] for i, h in enumerate(s.hulls)], np.int64).reshape(-1, 4)
+    return v, t, r
 
 
 def scene_to_arrays(s):
@@ -37,11 +46,14 @@ def scene_to_arrays(s):
     return bodies, cols
 
 
-def scene_from_arrays(bodies, cols, name="fixture", dt=1.0 / 120.0):
+def scene_from_arrays(bodies, cols, name="fixture", dt=1.0 / 120.0, hull_vertices=None, hull_triangles=None, hull_ranges=None):
     s = scenes.Scene(name, dt)
+    if hull_ranges is not None:
+        for v0, nv, t0, nt in hull_ranges:
+            s.add_hull_geometry(hull_vertices[v0:v0 + nv], hull_triangles[t0:t0 + nt])
     for b in bodies:
         s.add_body(b[0:3], b[3:7], kinematic=bool(b[7]), gravity_factor=float(b[8]), linear_damping=float(b[9]), angular_damping=float(b[10]))
-    nshape = {0: 4, 1: 7, 2: 7, 3: 6, 4: 10}
+    nshape = {0: 4, 1: 7, 2: 7, 3: 6, 4: 10, 5: 8}
     for c in cols:
         ctype = int(c[1])
         s.add_collider(int(c[0]), ctype, [np.float32(x) for x in c[2:2 + nshape[ctype]]], tuple(np.float32(c[12:15])), tuple(np.float32(c[15:18])), tuple(np.float32(c[18:22])))
@@ -53,6 +65,9 @@ def narrow_scene(seed=7321, per_pair=48, kinds=("sphere", "capsule", "aabb", "ob
     s = scenes.Scene("narrow_pairs")
     kinds = list(kinds)
     case = 0
+    geoms = []
+    if "hull" in kinds:
+        geoms = [s.add_hull_geometry(*scenes.hull_box(0.5, 0.35, 0.45)), s.add_hull_geometry(*scenes.hull_octahedron(0.6)), s.add_hull_geometry(*scenes.hull_icosahedron(0.55))]
 
     def shape(kind):
         if kind == "sphere":
@@ -63,6 +78,9 @@ def narrow_scene(seed=7321, per_pair=48, kinds=("sphere", "capsule", "aabb", "ob
         if kind == "cylinder":
             h = rng.between(0.3, 0.6)
             return CYLINDER, (0, -h, 0, 0, h, 0, rng.between(0.2, 0.5)), 1.0
+        if kind == "hull":
+            q = rng.unit_quat()
+            return HULL, (float(q[0]), float(q[1]), float(q[2]), float(q[3]), 0, 0, 0, float(geoms[int(rng.between(0, 2.999))])), 0.8
         he = (rng.between(0.3, 0.6), rng.between(0.3, 0.6), rng.between(0.3, 0.6))
         if kind == "aabb":
             return AABB, (-he[0], -he[1], -he[2], he[0], he[1], he[2]), 1.0
@@ -105,7 +123,8 @@ def gen_narrow(fname="narrow_pairs.npz", **kw):
     cpairs, counts = w.collisions()
     contacts, bp, ci = w.contacts()
     bodies, carr = scene_to_arrays(s)
-    np.savez_compressed(os.path.join(HERE, fname), bodies=bodies, colliders=carr, world_colliders=cols.view(np.uint8).reshape(len(cols), 64),
+    hv, ht, hr = hulls_to_arrays(s)
+    np.savez_compressed(os.path.join(HERE, fname), hull_vertices=hv, hull_triangles=ht, hull_ranges=hr, bodies=bodies, colliders=carr, world_colliders=cols.view(np.uint8).reshape(len(cols), 64),
                         aabbs=aabbs, pairs=pairs, colliding_pairs=cpairs, counts=counts, contacts=contacts.view(np.uint8).reshape(len(contacts), 32),
                         contact_collision=ci, mass=w.mass_properties())
     print(fname + ": %d bodies, %d pairs, %d collisions, %d contacts" % (len(bodies), len(pairs), len(cpairs), len(contacts)), orc.stats())
@@ -172,6 +191,7 @@ if __name__ == "__main__":
     orc.build()
     gen_narrow()
     gen_narrow("narrow_pairs_cylinder.npz", seed=99173, per_pair=64, kinds=("sphere", "capsule", "cylinder", "aabb", "obb"), only_with="cylinder")
+    gen_narrow("narrow_pairs_hull.npz", seed=40411, per_pair=64, kinds=("sphere", "capsule", "cylinder", "aabb", "obb", "hull"), only_with="hull")
     gen_scheduler()
     gen_trajectory("c1_trajectory.npz", scenes.c1_boxes(), (1, 60, 120, 240), (("scalar", orc.SOLVER_SCALAR), ("wide8", orc.SOLVER_WIDE8)))
     ragdoll = scenes.c4_ragdolls(1)

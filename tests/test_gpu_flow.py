@@ -21,7 +21,7 @@ def _world(mi, scene, flow):
             os.environ["MI_PHYSICS_NO_FLOW"] = old
 
 
-@pytest.mark.parametrize("name,steps", [("c3_mid", 150), ("c4_small", 60), ("shapes", 60)])
+@pytest.mark.parametrize("name,steps", [("c3_mid", 150), ("c4_small", 60), ("shapes_hull", 100)])
 def test_flow_equals_launch_sweep(mi, name, steps):
     from directx_renderer_kurth_amd import scenes
     scene = scenes.by_name(name)

@@ -44,7 +44,7 @@ def _run(mi, oracle, scene, steps, resync, vel_tol, pos_tol):
     return worst
 
 
-@pytest.mark.parametrize("name,steps", [("c1", 120), ("c2_small", 60), ("c3_small", 60), ("shapes", 90)])
+@pytest.mark.parametrize("name,steps", [("c1", 120), ("c2_small", 60), ("c3_small", 60), ("shapes", 90), ("shapes_hull", 150)])
 def test_follow_trajectory_contacts(mi, oracle, name, steps):
     """Free-running trajectories (the device world is never re-synchronised; errors accumulate).  Stated tolerances:
     pair SET exact (modulo the reference's endpoint-tie artefact, see parity_util); contact counts exact; contacts 1e-5;

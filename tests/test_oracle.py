@@ -20,10 +20,12 @@ def golden_tools():
     return make_golden
 
 
-def test_narrow_pairs_golden(oracle, golden_tools):
-    """Every in-scope intersection() pair on 48 seeded poses (incl. coincident centres, parallel capsules, SAT `parallel`)."""
-    g = load("narrow_pairs.npz")
-    s = golden_tools.scene_from_arrays(g["bodies"], g["colliders"])
+@pytest.mark.parametrize("fixture,num_type_pairs", [("narrow_pairs.npz", 10), ("narrow_pairs_cylinder.npz", 5), ("narrow_pairs_hull.npz", 6)])
+def test_narrow_pairs_golden(oracle, golden_tools, fixture, num_type_pairs):
+    """Every intersection() pair on 48-64 seeded poses (incl. coincident centres, parallel capsules / cylinders, SAT `parallel`):
+    the 10 sphere/capsule/box pairs, the 5 with a cylinder, the 6 with a convex hull."""
+    g = load(fixture)
+    s = golden_tools.scene_from_arrays(g["bodies"], g["colliders"], hull_vertices=g["hull_vertices"], hull_triangles=g["hull_triangles"], hull_ranges=g["hull_ranges"])
     w = s.instantiate(oracle.OracleWorld())
     w.step_internal(1e-9, 1)
     cols, aabbs = w.world_colliders()
@@ -35,10 +37,10 @@ def test_narrow_pairs_golden(oracle, golden_tools):
     contacts = w.contacts()[0]
     assert np.array_equal(contacts.view(np.uint8).reshape(len(contacts), 32), g["contacts"])
     np.testing.assert_array_equal(w.mass_properties(), g["mass"])
-    # all 10 type pairs are exercised and produce contacts
+    # all type pairs of the fixture are exercised and produce contacts
     types = cols["type"]
     seen = {(int(types[a]), int(types[b])) for a, b in cpairs}
-    assert len(seen) == 10, seen
+    assert len(seen) == num_type_pairs, seen
 
 
 def test_narrow_contact_invariants(oracle):
@@ -175,3 +177,26 @@ def test_physics_step_accumulator(oracle):
     np.testing.assert_allclose(ti[:, :3], t0[:, :3] + a * (t1[:, :3] - t0[:, :3]), atol=1e-6)
     w.step(1.0, st)                                                         # 4 sub-steps max, remainder dropped by fmod
     assert w.timer.value < 1 / 120.0
+
+
+def test_hull_mass_properties_and_contact(oracle):
+    """Convex hulls: the tetrahedron-covariance mass properties of a box-shaped hull equal the closed-form box
+    (physics.cpp:1520-1580 vs :1496-1502), and sphere-vs-hull GJK + EPA gives the face normal and the penetration depth (within EPA's
+    own 0.01 stop criterion, collision_epa.h:139)."""
+    from directx_renderer_kurth_amd import scenes
+    w = oracle.OracleWorld()
+    g = w.add_hull_geometry(*scenes.hull_box(0.5, 0.35, 0.45))
+    hb = w.add_body((0, 0, 0))
+    w.add_collider(hb, 5, (0, 0, 0, 1, 0, 0, 0, float(g)), (0.1, 0.5, 2.0))
+    bb = w.add_body((3, 0, 0))
+    w.add_collider(bb, 4, (0, 0, 0, 1, 0, 0, 0, 0.5, 0.35, 0.45), (0.1, 0.5, 2.0))
+    mp = w.mass_properties()
+    np.testing.assert_allclose(mp[hb], mp[bb], rtol=2e-5, atol=1e-6)          # {localCOG, invMass, invInertia}
+    assert abs(1.0 / mp[hb][3] - 2.0 * 1.0 * 0.7 * 0.9) < 1e-5
+    sb = w.add_body((0, 0.35 + 0.3 - 0.05, 0))                                # sphere r = 0.3 resting 5 cm inside the top face
+    w.add_collider(sb, 0, (0, 0, 0, 0.3), (0.1, 0.5, 1.0))
+    w.step_internal(1e-9, 1)
+    contacts, bp, ci = w.contacts()
+    assert len(contacts) == 1
+    n = contacts["normal"][0]; d = contacts["depth"][0]
+    assert abs(abs(n[1]) - 1.0) < 1e-3 and abs(d - 0.05) < 0.011
