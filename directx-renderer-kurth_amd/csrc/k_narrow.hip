@@ -45,7 +45,7 @@ __global__ void k_bucket_offsets(u32* __restrict__ counters, const u32* __restri
 	u32 lo = 0, hi = n;
 	while (lo < hi) { u32 mid = (lo + hi) >> 1; if (keySorted[mid] < b) lo = mid + 1; else hi = mid; }
 	counters[CTR_BUCKET_START + b] = lo; // valid keys are <= 4*6+4 = 28; KEY_INVALID sorts last
-	if (b == KEY_INVALID) { counters[CTR_NUM_VALID] = lo; counters[CTR_EPA_COUNT] = 0; counters[CTR_NUM_ACTIVE] = 0; counters[CTR_NUM_CONTACTS] = 0; }
+	if (b == KEY_INVALID) { counters[CTR_NUM_VALID] = lo; counters[CTR_EPA_COUNT] = 0; counters[CTR_EPA_COUNT_HULL] = 0; counters[CTR_NUM_ACTIVE] = 0; counters[CTR_NUM_CONTACTS] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -603,8 +603,13 @@ MI_DEV V3 hullSupport(const Hull& h, const float4* __restrict__ hullVerts, V3 di
 // B: axis-aligned box, cylinder or hull.
 enum { SUP_CAPSULE = 0, SUP_CYLINDER = 1, SUP_SPHERE = 2, SUP_BOX = 3, SUP_OBB = 4, SUP_HULL = 5 };
 struct SupShapes { Capsule tubeA, tubeB; Box box, boxA; Obb obbA; Hull hullA, hullB; u32 kindA, kindB; const float4* hullVerts; };
+// FAMILY 0: tube (capsule / cylinder) vs box or cylinder — the pairs of the BASELINE configs; FAMILY 1: anything vs hull.  Separate
+// kernel instances: with the family fixed at compile time the unused shapes drop out of the registers (one build for everything
+// needed 256 VGPRs and halved the occupancy of the tube pairs).
+template <int FAMILY>
 MI_DEV V3 supportA(const SupShapes& sh, V3 dir)
 {
+	if (FAMILY == 0) return (sh.kindA == SUP_CYLINDER) ? cylinderSupport(sh.tubeA, dir) : capsuleSupport(sh.tubeA, dir);
 	switch (sh.kindA)
 	{
 		case SUP_CAPSULE: return capsuleSupport(sh.tubeA, dir);
@@ -615,11 +620,13 @@ MI_DEV V3 supportA(const SupShapes& sh, V3 dir)
 		default: return hullSupport(sh.hullA, sh.hullVerts, dir);
 	}
 }
+template <int FAMILY>
 MI_DEV SupportPoint supportPair(const SupShapes& sh, V3 dir)
 {
 	SupportPoint s;
-	s.a = supportA(sh, dir);
-	s.b = (sh.kindB == SUP_BOX) ? boxSupport(sh.box, -dir) : ((sh.kindB == SUP_CYLINDER) ? cylinderSupport(sh.tubeB, -dir) : hullSupport(sh.hullB, sh.hullVerts, -dir));
+	s.a = supportA<FAMILY>(sh, dir);
+	if (FAMILY == 0) s.b = (sh.kindB == SUP_BOX) ? boxSupport(sh.box, -dir) : cylinderSupport(sh.tubeB, -dir);
+	else s.b = hullSupport(sh.hullB, sh.hullVerts, -dir);
 	s.mk = s.a - s.b;
 	return s;
 }
@@ -682,20 +689,21 @@ MI_DEV int updateGJKSimplex(GjkSimplex& s, const SupportPoint& a, V3& dir)
 	return 2;
 }
 
+template <int FAMILY>
 MI_DEV bool gjkPair(const SupShapes& sh, GjkSimplex& sx)
 {
 	V3 dir = v3(1.f, 0.1f, -0.2f);
-	sx.c = supportPair(sh, dir);
+	sx.c = supportPair<FAMILY>(sh, dir);
 	if (dot(sx.c.mk, dir) < 0.f) return false;
 	dir = -sx.c.mk;
-	sx.b = supportPair(sh, dir);
+	sx.b = supportPair<FAMILY>(sh, dir);
 	if (dot(sx.b.mk, dir) < 0.f) return false;
 	dir = crossABA(sx.c.mk - sx.b.mk, -sx.b.mk);
 	sx.numPoints = 2;
 	for (u32 it = 0; it < GJK_MAX_ITERATIONS; ++it)
 	{
 		if (sqlen(dir) < 0.0001f) return false;
-		SupportPoint a = supportPair(sh, dir);
+		SupportPoint a = supportPair<FAMILY>(sh, dir);
 		if (dot(a.mk, dir) < 0.f) return false;
 		int res = updateGJKSimplex(sx, a, dir);
 		if (res == 0) { sx.a = a; sx.numPoints = 4; return true; }
@@ -749,6 +757,7 @@ __device__ __forceinline__ void epaSetTri(EpaWave& e, u32 t, u32 a, u32 b, u32 c
 }
 
 // Runs on a full wave; every lane returns the same (point, normal, depth).
+template <int FAMILY>
 __device__ void epaWave(EpaWave& e, u32 lane, const GjkSimplex& g, const SupShapes& sh, V3& outPoint, V3& outNormal, float& outDepth)
 {
 	u32 numTris = 4, numPoints = 4, numEdges = 6;
@@ -778,7 +787,7 @@ __device__ void epaWave(EpaWave& e, u32 lane, const GjkSimplex& g, const SupShap
 		closest = bi;
 		if (closest == 0xFFFFFFFFu) { closest = 0; break; }
 		V3 tn = v3(e.tnx[closest], e.tny[closest], e.tnz[closest]);
-		SupportPoint np = supportPair(sh, tn);
+		SupportPoint np = supportPair<FAMILY>(sh, tn);
 		float dd = dot(np.mk, tn);
 		if (dd - e.tdist[closest] < 0.01f) break;
 
@@ -889,6 +898,7 @@ MI_DEV Hull asHull(const ColliderRec& c, const float4* __restrict__ hullInfo)
 // Operands of one GJK/EPA instance by bucket key: 9 capsule-aabb, 10 capsule-obb, 14 cylinder-cylinder, 15 cylinder-aabb,
 // 16 cylinder-obb (the obb variants work in the box's frame, :771-790, :1024-1043), and x-hull for x = 5 sphere, 11 capsule,
 // 17 cylinder, 23 aabb, 29 obb, 35 hull.
+template <int FAMILY>
 MI_DEV void gjkOperands(u32 key, const ColliderRec& A, const ColliderRec& B, const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts, SupShapes& sh, Obb& o)
 {
 	sh.hullVerts = hullVerts;
@@ -897,7 +907,7 @@ MI_DEV void gjkOperands(u32 key, const ColliderRec& A, const ColliderRec& B, con
 	sh.obbA.q = q4(0.f, 0.f, 0.f, 1.f); sh.obbA.c = v3s(0.f); sh.obbA.r = v3s(0.f);
 	sh.hullA.q = sh.obbA.q; sh.hullA.pos = v3s(0.f); sh.hullA.first = 0; sh.hullA.count = 0; sh.hullB = sh.hullA;
 	sh.kindA = (key >= 14) ? SUP_CYLINDER : SUP_CAPSULE; sh.kindB = SUP_BOX;
-	if (key % 6 == 5) // x vs hull
+	if (FAMILY == 1) // x vs hull
 	{
 		sh.kindB = SUP_HULL; sh.hullB = asHull(B, hullInfo);
 		switch (key / 6)
@@ -984,18 +994,20 @@ __global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(con
 // occur; 11 is a hull pair, 12 and 13 cannot occur with typeA <= typeB).  Parallel cylinder pairs finish here in closed form.  Misses write
 // their empty manifold; hits append (slot, simplex) to the EPA work list so that phase 2 runs with dense waves — the
 // expanding polytope needs ~3.7 KB of private scratch per lane and 20 serial iterations, which must not idle behind misses.
+template <int FAMILY>
 __global__ void __launch_bounds__(256) k_gjk(u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
 	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, u32* __restrict__ epaList, float4* __restrict__ gjkSimplex,
-	const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts)
+	const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts, u32 listCap)
 {
-	u32 slot = counters[CTR_BUCKET_START + 5] + blockIdx.x * blockDim.x + threadIdx.x; // keys 5..35; the closed-form and box keys in between are skipped
-	if (slot >= counters[CTR_BUCKET_START + 36]) return;
+	// family 0: the contiguous slot range of keys 9..16 (11 = capsule-hull is skipped); family 1: keys 5..35 with key % 6 == 5
+	u32 slot = counters[CTR_BUCKET_START + (FAMILY == 0 ? 9 : 5)] + blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= counters[CTR_BUCKET_START + (FAMILY == 0 ? 17 : 36)]) return;
 	u32 key = keySorted[slot];
-	if (!gjkKey(key)) return;
+	if (FAMILY == 0 ? (key % 6 == 5) : (key % 6 != 5)) return;
 	u64 packed = pairSorted[slot];
 	ColliderRec A = colWorld[(u32)packed], B = colWorld[(u32)(packed >> 32)];
 	SupShapes sh; Obb o;
-	gjkOperands(key, A, B, hullInfo, hullVerts, sh, o);
+	gjkOperands<FAMILY>(key, A, B, hullInfo, hullVerts, sh, o);
 	if (key == 14)
 	{
 		Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
@@ -1003,13 +1015,14 @@ __global__ void __launch_bounds__(256) k_gjk(u32* __restrict__ counters, const u
 		if (r != 2) { writeManifold(manifolds, slot, m, r == 1, A, B, slot); return; }
 	}
 	GjkSimplex sx;
-	if (!gjkPair(sh, sx))
+	if (!gjkPair<FAMILY>(sh, sx))
 	{
 		Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
 		writeManifold(manifolds, slot, m, false, A, B, slot);
 		return;
 	}
-	u32 j = atomicAdd(&counters[CTR_EPA_COUNT], 1u); // order of the work list does not affect any result
+	u32 j = atomicAdd(&counters[FAMILY == 0 ? CTR_EPA_COUNT : CTR_EPA_COUNT_HULL], 1u); // order of the work list does not affect any result
+	if (FAMILY == 1) j = listCap - 1u - j; // the hull pairs fill the list from its end
 	epaList[j] = slot;
 	float4* S = gjkSimplex + (size_t)j * 9;
 	const SupportPoint* P[4] = { &sx.a, &sx.b, &sx.c, &sx.d };
@@ -1021,23 +1034,25 @@ __global__ void __launch_bounds__(256) k_gjk(u32* __restrict__ counters, const u
 
 // Phase 2: EPA (one wave per hit, polytope in LDS) + face clipping (lane 0) for every GJK hit.  Waves stride over the work list.
 #define EPA_WAVES_PER_BLOCK 4
+template <int FAMILY>
 __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) k_epa(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
 	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, const u32* __restrict__ epaList, const float4* __restrict__ gjkSimplex,
-	const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts)
+	const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts, u32 listCap)
 {
 	__shared__ EpaWave shared[EPA_WAVES_PER_BLOCK];
 	u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	EpaWave& e = shared[wave];
-	u32 numHits = counters[CTR_EPA_COUNT];
+	u32 numHits = counters[FAMILY == 0 ? CTR_EPA_COUNT : CTR_EPA_COUNT_HULL];
 	u32 stride = gridDim.x * EPA_WAVES_PER_BLOCK;
-	for (u32 j = blockIdx.x * EPA_WAVES_PER_BLOCK + wave; j < numHits; j += stride)
+	for (u32 jj = blockIdx.x * EPA_WAVES_PER_BLOCK + wave; jj < numHits; jj += stride)
 	{
+		u32 j = (FAMILY == 0) ? jj : listCap - 1u - jj;
 		u32 slot = epaList[j];
 		u32 key = keySorted[slot];
 		u64 packed = pairSorted[slot];
 		ColliderRec A = colWorld[(u32)packed], B = colWorld[(u32)(packed >> 32)];
 		SupShapes sh; Obb o;
-		gjkOperands(key, A, B, hullInfo, hullVerts, sh, o);
+		gjkOperands<FAMILY>(key, A, B, hullInfo, hullVerts, sh, o);
 		const float4* S = gjkSimplex + (size_t)j * 9;
 		float f[36];
 		for (u32 i = 0; i < 9; ++i) { float4 v = S[i]; f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w; }
@@ -1045,11 +1060,11 @@ __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) k_epa(const u32* __r
 		SupportPoint* P[4] = { &sx.a, &sx.b, &sx.c, &sx.d };
 		for (u32 i = 0; i < 4; ++i) { P[i]->a = v3(f[9 * i], f[9 * i + 1], f[9 * i + 2]); P[i]->b = v3(f[9 * i + 3], f[9 * i + 4], f[9 * i + 5]); P[i]->mk = v3(f[9 * i + 6], f[9 * i + 7], f[9 * i + 8]); }
 		V3 point, normal; float depth;
-		epaWave(e, lane, sx, sh, point, normal, depth);
+		epaWave<FAMILY>(e, lane, sx, sh, point, normal, depth);
 		if (lane == 0)
 		{
 			Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
-			if (key == 14 || key % 6 == 5) { m.n = normal; m.count = 1; m.p[0] = make_float4(point.x, point.y, point.z, depth); } // :905-950; hull pairs
+			if (FAMILY == 1 || key == 14) { m.n = normal; m.count = 1; m.p[0] = make_float4(point.x, point.y, point.z, depth); } // :905-950; hull pairs
 			else capsuleBoxFinish(point, normal, depth, sh.tubeA, sh.box, m);
 			if (key == 10 || key == 16) // back to world space (:779-787, :1032-1040)
 			{
@@ -1074,9 +1089,14 @@ void launch_narrowphase(World& w, u32 numPairs)
 	csort_pairs_u64(w, w.pairKey.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p + numPairs, (u64*)w.pairsSorted.p, numPairs, 64);
 	hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p);
 	const u64* sortedPairs = (const u64*)w.pairsSorted.p;
-	hipLaunchKernelGGL(k_gjk, grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p);
+	u32 listCap = (u32)w.pairCap;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gjk<0>), grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
+	if (!w.hulls.empty())
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gjk<1>), grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_CLOSED>), grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_BOX>), dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p);
 	u32 epaBlocks = std::min<u32>((numPairs + EPA_WAVES_PER_BLOCK - 1) / EPA_WAVES_PER_BLOCK, 256u * 4u); // 4 blocks of 4 waves (38.5 KB of LDS each) fit a CU
-	hipLaunchKernelGGL(k_epa, dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p);
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epa<0>), dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
+	if (!w.hulls.empty())
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epa<1>), dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
 }

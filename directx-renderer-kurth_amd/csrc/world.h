@@ -72,6 +72,7 @@ enum
 	CTR_PAIR_OVERFLOW = 11, // some collider has more broadphase partners than its slab holds
 	CTR_FIRST_INACTIVE = 12,// sorted position of the first collider whose body is simulated by another GPU
 	CTR_FLOW_STATUS = 13,   // dataflow sweep: non-zero = a lane gave up waiting (result invalid); cleared by k_color_offsets
+	CTR_EPA_COUNT_HULL = 15,// GJK hits among the hull pairs (their EPA work list grows from the end of epaList)
 	CTR_FLOW_PROBES = 14,   // dataflow sweep: number of record polls of the step (must directly follow CTR_FLOW_STATUS)
 	CTR_BUCKET_START = 16,  // 65 words: first slot of narrowphase bucket key b (tA*6+tB); [64] unused
 	CTR_KEY_START = 96,     // (MI_MAX_COLORS+1)*4 + 1 words: first schedule slot of key colour*4 + (4-count); last = numManifolds
