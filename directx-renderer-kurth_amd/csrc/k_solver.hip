@@ -364,7 +364,8 @@ void launch_coloring(World& w, u32 numPairs)
 			MI_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w.device));
 			w.colorMaxBlocks = (u32)std::max(1, std::min(perCU, 1)) * (u32)std::max(1, cus); // one 1024-lane workgroup per CU: few barrier arrivals
 		}
-		u32 blocks = std::min<u32>(std::max(1u, (est + 1023) / 1024), w.colorMaxBlocks);
+		// two manifolds per lane: half the barrier arrivals per round, and the second manifold's loads hide behind the first's (measured: -35 us at 120k manifolds)
+		u32 blocks = std::min<u32>(std::max(1u, (est + 2047) / 2048), w.colorMaxBlocks);
 		hipLaunchKernelGGL(k_color_all, dim3(blocks), dim3(1024), 0, w.stream, w.dCounters.p, nb, 1024u, w.actIds.p, w.mColor.p, w.bodyMask.p, w.claim.p);
 	}
 	else
