@@ -48,7 +48,7 @@ class WorldDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("numRigidBodies", C.c_uint32), ("numColliders", C.c_uint32), ("numBroadphaseOverlaps", C.c_uint32), ("numCollisions", C.c_uint32),
                 ("numContacts", C.c_uint32), ("numColors", C.c_uint32), ("numJoints", C.c_uint32), ("numInternalSteps", C.c_uint32),
-                ("numGraphBuilds", C.c_uint32), ("coloringRounds", C.c_uint32), ("flowProbes", C.c_uint32),
+                ("numGraphBuilds", C.c_uint32), ("coloringRounds", C.c_uint32), ("flowProbes", C.c_uint32), ("numFlowRecoveries", C.c_uint32),
                 ("msCollidersBroad", C.c_float), ("msNarrow", C.c_float), ("msSolverSetup", C.c_float), ("msSolve", C.c_float),
                 ("msIntegrate", C.c_float), ("msTotal", C.c_float)]
 

@@ -210,10 +210,11 @@ void launch_integrate_forces(World& w, float dt)
 // K13: velocity integration.  Reads cog(16) + vel(32) + rot(16) + localCOG(16), writes pose(32) + clears accumulators.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_integrate_velocities(u32 nb, float dt, float4* __restrict__ pose, const float4* __restrict__ bprops,
-	const float4* __restrict__ vel, const float4* __restrict__ cog, const uint8_t* __restrict__ simMask, float4* __restrict__ force)
+	const float4* __restrict__ vel, const float4* __restrict__ cog, const uint8_t* __restrict__ simMask, float4* __restrict__ force, const u32* __restrict__ flowStatus)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nb || !simMask[i]) return;
+	if (*flowStatus) return; // the dataflow sweep gave up: velocities are invalid, the host redoes the solve and this integration (World::recoverFlow)
 	Q4 grot = q4f4(pose[2 * i + 1]);
 	V3 gpos = v3f4(cog[i]);
 	V3 v = v3f4(vel[2 * i]), wv = v3f4(vel[2 * i + 1]);
@@ -232,7 +233,7 @@ __global__ void __launch_bounds__(256) k_integrate_velocities(u32 nb, float dt, 
 void launch_integrate_velocities(World& w, float dt)
 {
 	if (!w.nb) return;
-	hipLaunchKernelGGL(k_integrate_velocities, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.vel.p, w.cog.p, w.simMask.p, w.force.p);
+	hipLaunchKernelGGL(k_integrate_velocities, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.vel.p, w.cog.p, w.simMask.p, w.force.p, w.dCounters.p + CTR_FLOW_STATUS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -891,6 +891,12 @@ void launch_solve_flow(World& w, u32 numManifolds, u32 itBegin, u32 itEnd, u32 f
 		w.flowEpoch = 0;
 	}
 	w.flowEpoch++;
+	if (w.flowTestAbortStep == w.stats.numInternalSteps) // tests: pretend a lane timed out; everybody drains without solving
+	{
+		u32 one = 16u;
+		MI_CHECK(hipMemcpyAsync(w.dCounters.p + CTR_FLOW_STATUS, &one, sizeof(u32), hipMemcpyHostToDevice, w.stream));
+		MI_CHECK(hipStreamSynchronize(w.stream));
+	}
 	u32 regions = firstColor ? 1u : flow_num_regions(w);
 	// One lane per manifold whenever the 3-blocks-per-CU build can hold them all; beyond that lanes take several manifolds each and
 	// the spill-free 2-blocks-per-CU build measured faster.  With regions every XCD must be able to hold its whole region: full grid.

@@ -132,6 +132,11 @@ struct World
 	DevBuf<u64> flowTrace;                // developer timeline (mi_debug_flow_trace): 32 x u64 per slot, allocated on request only
 	u32 flowEpoch = 0, flowMaxBlocks[2] = { 0, 0 };
 	bool useFlow = true;                  // MI_PHYSICS_NO_FLOW=1: launch-per-colour sweep only
+	// Safety net of the persistent kernels: if one gives up waiting (only possible when the GPU is shared with another persistent
+	// kernel), the step's velocity integration is skipped on the device and the host redoes solve + integration with the launch
+	// sweep from the saved pre-solve velocities, at the next point where it synchronises anyway.
+	DevBuf<float4> velBackup; bool flowPending = false; float pendingDt = 0.f; u32 pendingIters = 0, flowCooldown = 0, flowTestAbortStep = ~0u;
+	void recoverFlow(); int resolvePendingFlow();
 	u32 flowHopTicks = 100, flowBackoffCap = 64, flowPredictFrac = 192; // poll pacing: 10 ns ticks; fraction (/256) of the iteration period slept through (MI_FLOW_HOP / _CAP / _PREDICT)
 	DevBuf<uint8_t> tempStorage;
 	DevBuf<u32> sortHist;                 // counting sort: per-tile bucket histograms + their scan

@@ -52,6 +52,7 @@ World::World(int dev) : device(dev)
 	useFusedColoring = getenv("MI_PHYSICS_NO_FUSED_COLORING") == nullptr;
 	if (const char* e = getenv("MI_FLOW_MAX")) flowMaxManifolds = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_EAGER")) flowEagerMax = (u32)atoi(e);
+	if (const char* e = getenv("MI_FLOW_TEST_ABORT")) flowTestAbortStep = (u32)atoi(e); // tests: make the dataflow sweep of that internal step give up
 	if (const char* e = getenv("MI_FLOW_HOP")) flowHopTicks = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_CAP")) flowBackoffCap = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_PREDICT")) flowPredictFrac = (u32)atoi(e);
@@ -249,6 +250,7 @@ static u32 nextPow2(u32 v) { u32 p = 1; while (p < v) p <<= 1; return p; }
 void World::downloadState()
 {
 	if (!stateOnDevice || !nb) return;
+	resolvePendingFlow();
 	std::vector<float4> hp(2 * (size_t)nb), hv(2 * (size_t)nb), hf(2 * (size_t)nb);
 	MI_CHECK(hipMemcpyAsync(hp.data(), pose.p, sizeof(float4) * hp.size(), hipMemcpyDeviceToHost, stream));
 	MI_CHECK(hipMemcpyAsync(hv.data(), vel.p, sizeof(float4) * hv.size(), hipMemcpyDeviceToHost, stream));
@@ -507,6 +509,40 @@ static void runSolverSweep(World& w, u32 iters, u32 numColors)
 	if (g.exec) MI_CHECK(hipGraphLaunch(g.exec, w.stream));
 }
 
+// The dataflow sweep of the last step gave up (CTR_FLOW_STATUS != 0): its velocities are garbage and k_integrate_velocities skipped
+// itself.  hCounters still describes that step's schedule.  Restore the pre-solve velocities, clear the accumulated impulses and
+// run joints + contacts as launches, then integrate.  The dataflow stays off for a while.
+void World::recoverFlow()
+{
+	stats.numFlowRecoveries++;
+	flowCooldown = 256;
+	MI_CHECK(hipMemsetAsync(dCounters.p + CTR_FLOW_STATUS, 0, sizeof(u32), stream));
+	MI_CHECK(hipMemcpyAsync(vel.p, velBackup.p, sizeof(float4) * 2 * ((size_t)nb + 1), hipMemcpyDeviceToDevice, stream));
+	if (rowCap) MI_CHECK(hipMemsetAsync(rowLambda.p, 0, sizeof(float2) * (size_t)MI_MAX_CONTACTS_PER_MANIFOLD * rowCap, stream));
+	launch_joint_init(*this, pendingDt);
+	bool flow = useFlow; useFlow = false;
+	runSolverSweep(*this, pendingIters, hCounters[CTR_NUM_PAIRS] ? hCounters[CTR_NUM_COLORS] : 0);
+	useFlow = flow;
+	launch_integrate_velocities(*this, pendingDt);
+}
+
+// Before the host looks at results: has the last step's dataflow sweep completed?  (One extra 4-byte read, only after a dataflow step.)
+int World::resolvePendingFlow()
+{
+	if (!flowPending) return lastError;
+	flowPending = false;
+	u32 status = 0;
+	MI_CHECK(hipMemcpyAsync(&status, dCounters.p + CTR_FLOW_STATUS, sizeof(u32), hipMemcpyDeviceToHost, stream));
+	MI_CHECK(hipStreamSynchronize(stream));
+	if (status)
+	{
+		readCounters(*this);
+		recoverFlow();
+		MI_CHECK(hipStreamSynchronize(stream));
+	}
+	return lastError;
+}
+
 int World::stepInternal(float dt, u32 iters)
 {
 	g_currentWorld = this;
@@ -521,13 +557,21 @@ int World::stepInternal(float dt, u32 iters)
 	launch_build_colliders(*this);
 	launch_broadphase_count(*this);
 	readCounters(*this);                                   // sync #1: number of overlapping pairs
-	if (hCounters[CTR_FLOW_STATUS])                        // the previous step's dataflow sweep gave up waiting: its result is invalid
+	if (hCounters[CTR_FLOW_STATUS])                        // a persistent kernel of the previous step gave up waiting
 	{
-		useFlow = false;
-		useFusedColoring = false;
-		fail(MI_ERR_HIP, "a persistent kernel gave up waiting (status " + std::to_string(hCounters[CTR_FLOW_STATUS]) + ": 1 = contact hand-over, 2 = XCD census, 4 = unserved XCD region, 8 = colouring barrier; GPU shared with another persistent kernel?); set MI_PHYSICS_NO_FLOW=1 MI_PHYSICS_NO_FUSED_COLORING=1");
-		return lastError;
+		if (hCounters[CTR_FLOW_STATUS] & 8u) // the colouring barrier: the schedule itself is incomplete, nothing to redo it from
+		{
+			useFusedColoring = false;
+			fail(MI_ERR_HIP, "the fused colouring kernel gave up waiting at its grid barrier (GPU shared with another persistent kernel?); set MI_PHYSICS_NO_FUSED_COLORING=1");
+			return lastError;
+		}
+		flowPending = false;
+		recoverFlow();                                     // redo the previous step's solve + integration with the launch sweep
+		launch_build_colliders(*this);                     // ... and this step's start, which ran on the stale poses
+		launch_broadphase_count(*this);
+		readCounters(*this);
 	}
+	flowPending = false;
 	stats.flowProbes = hCounters[CTR_FLOW_PROBES];
 	u32 numPairs = hCounters[CTR_NUM_PAIRS];
 	ensurePairBuffers(*this, numPairs);
@@ -555,7 +599,19 @@ int World::stepInternal(float dt, u32 iters)
 	else { memset(hCounters + CTR_KEY_START, 0, sizeof(u32) * (MI_NUM_SCHEDULE_KEYS + 1)); hCounters[CTR_NUM_MANIFOLDS] = 0; hCounters[CTR_NUM_VALID] = 0; lastNumManifolds = 0; }
 	if (T) MI_CHECK(hipEventRecord(stageEvents[3], stream));
 
-	runSolverSweep(*this, iters, numPairs ? numColors : 0);
+	if (flowCooldown) --flowCooldown;
+	bool flowStep = useFlow && !flowCooldown && numPairs && numColors;
+	if (flowStep) // pre-solve velocities, in case the dataflow sweep has to be redone (World::recoverFlow)
+	{
+		velBackup.ensure(2 * ((size_t)nb + 1), stream);
+		MI_CHECK(hipMemcpyAsync(velBackup.p, vel.p, sizeof(float4) * 2 * ((size_t)nb + 1), hipMemcpyDeviceToDevice, stream));
+		pendingDt = dt; pendingIters = iters; flowPending = true;
+	}
+	{
+		bool flow = useFlow; useFlow = flowStep;
+		runSolverSweep(*this, iters, numPairs ? numColors : 0);
+		useFlow = flow;
+	}
 	if (T) MI_CHECK(hipEventRecord(stageEvents[4], stream));
 
 	launch_integrate_velocities(*this, dt);
@@ -598,6 +654,7 @@ int World::step(float* timer, const mi_physics_settings* s, float dt)
 			}
 		}
 		if (*timer >= fixedDt) *timer = fmodf(*timer, fixedDt);
+		resolvePendingFlow(); // the interpolation reads the final poses
 		launch_lerp_pose(*this, *timer / fixedDt);
 	}
 	else
@@ -838,6 +895,7 @@ int mi_delete_all_constraints(mi_world* world)
 int mi_apply_force_torque(mi_world* world, uint32_t body, const float f[3], const float t[3])
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
 	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
 	if (W->stateOnDevice && !W->topologyDirty && body < W->nb)
 	{
@@ -852,6 +910,7 @@ int mi_apply_force_torque(mi_world* world, uint32_t body, const float f[3], cons
 int mi_set_velocity(mi_world* world, uint32_t body, const float lin[3], const float ang[3])
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
 	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
 	World::HBody& b = W->bodies[body];
 	if (W->stateOnDevice && !W->topologyDirty && body < W->nb)
@@ -865,6 +924,7 @@ int mi_set_velocity(mi_world* world, uint32_t body, const float lin[3], const fl
 int mi_set_transform(mi_world* world, uint32_t body, const float pos[3], const float rot[4])
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
 	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
 	if (W->stateOnDevice && !W->topologyDirty && body < W->nb)
 	{
@@ -880,6 +940,7 @@ int mi_set_transform(mi_world* world, uint32_t body, const float pos[3], const f
 int mi_write_transforms(mi_world* world, const float* in7, uint32_t n)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
 	W->upload();
 	n = std::min<u32>(n, W->nb);
 	if (!n) return W->lastError;
@@ -898,6 +959,7 @@ int mi_write_transforms(mi_world* world, const float* in7, uint32_t n)
 int mi_write_velocities(mi_world* world, const float* in6, uint32_t n)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
 	W->upload();
 	n = std::min<u32>(n, W->nb);
 	if (!n) return W->lastError;
@@ -925,11 +987,12 @@ int mi_step_internal(mi_world* world, float dt, uint32_t iterations)
 	if (!e && W->nb) MI_CHECK(hipMemcpyAsync(W->poseLerp.p, W->pose.p, sizeof(float4) * 2 * W->nb, hipMemcpyDeviceToDevice, W->stream));
 	return e ? e : W->lastError;
 }
-int mi_synchronize(mi_world* world) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); MI_CHECK(hipStreamSynchronize(W->stream)); return W->lastError; }
+int mi_synchronize(mi_world* world) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); MI_CHECK(hipStreamSynchronize(W->stream)); return W->resolvePendingFlow(); }
 
 int mi_read_transforms(mi_world* world, uint32_t which, float* out7, uint32_t n)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
 	W->upload();
 	n = std::min<u32>(n, W->nb);
 	if (!n) return W->lastError;
@@ -946,6 +1009,7 @@ int mi_read_transforms(mi_world* world, uint32_t which, float* out7, uint32_t n)
 int mi_read_velocities(mi_world* world, float* out6, uint32_t n)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
 	W->upload();
 	n = std::min<u32>(n, W->nb);
 	if (!n) return W->lastError;
@@ -977,6 +1041,7 @@ uint32_t mi_num_colliders(mi_world* world) { CHECK_WORLD(0); return (u32)W->coll
 int mi_device_pointers(mi_world* world, void** pose, void** vel, void** stream)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
 	W->upload();
 	if (pose) *pose = W->pose.p; if (vel) *vel = W->vel.p; if (stream) *stream = (void*)W->stream;
 	return W->lastError;
@@ -986,6 +1051,7 @@ int mi_device_pointers(mi_world* world, void** pose, void** vel, void** stream)
 int mi_state_to_device_buffers(mi_world* world, void* dPose, void* dVel)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
 	W->upload();
 	if (!W->nb) return W->lastError;
 	MI_CHECK(hipMemcpyAsync(dPose, W->pose.p, sizeof(float4) * 2 * W->nb, hipMemcpyDeviceToDevice, W->stream));
@@ -996,6 +1062,7 @@ int mi_state_to_device_buffers(mi_world* world, void* dPose, void* dVel)
 int mi_state_from_device_buffers(mi_world* world, const void* dPose, const void* dVel, const uint8_t* dMask)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
 	W->upload();
 	if (!W->nb) return W->lastError;
 	if (dPose) MI_CHECK(hipMemcpyAsync(W->pose.p, dPose, sizeof(float4) * 2 * W->nb, hipMemcpyDeviceToDevice, W->stream));
@@ -1007,6 +1074,7 @@ int mi_state_from_device_buffers(mi_world* world, const void* dPose, const void*
 // ---- inspection ----
 static void d2h(World* w, void* dst, const void* src, size_t bytes)
 {
+	w->resolvePendingFlow();
 	if (!bytes) return;
 	MI_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, w->stream)); MI_CHECK(hipStreamSynchronize(w->stream));
 }

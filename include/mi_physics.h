@@ -63,6 +63,7 @@ typedef struct mi_stats
 	uint32_t numColors, numJoints, numInternalSteps;
 	uint32_t numGraphBuilds, coloringRounds; /* solver-sweep hipGraph (re)builds so far; colouring round budget of the last step */
 	uint32_t flowProbes;                     /* dataflow contact sweep: body-record polls of the step before the last one (0 = launch sweep) */
+	uint32_t numFlowRecoveries;              /* steps whose dataflow sweep gave up and was redone with the launch sweep (should stay 0) */
 	float msCollidersBroad, msNarrow, msSolverSetup, msSolve, msIntegrate, msTotal; /* HIP-event times, only when timing is enabled */
 } mi_stats;
 

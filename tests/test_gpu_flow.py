@@ -37,3 +37,24 @@ def test_flow_equals_launch_sweep(mi, name, steps):
             assert np.array_equal(wf.velocities(), wl.velocities()), "step %d" % i
     assert used_flow
     assert wf.stats()["numCollisions"] > 0
+
+
+@pytest.mark.parametrize("abort_step,steps", [(50, 60), (11, 12)])
+def test_flow_abort_is_recovered(mi, abort_step, steps):
+    """Safety net of the persistent kernel: if the dataflow sweep of a step gives up (injected here), the device skips that step's
+    integration and the host redoes solve + integration with the launch sweep from the saved pre-solve velocities — at the next
+    step's first synchronisation (abort in the middle of the run) or when results are read (abort in the last step).  The trajectory
+    must equal the launch-sweep one bit for bit."""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name("c4_small" if abort_step == 50 else "c3_small")   # ragdolls (joints + ground contacts by step 50) / a pile
+    os.environ["MI_FLOW_TEST_ABORT"] = str(abort_step)
+    try:
+        wf = _world(mi, scene, True)
+    finally:
+        os.environ.pop("MI_FLOW_TEST_ABORT", None)
+    wl = _world(mi, scene, False)
+    for i in range(steps):
+        wf.step_internal(scene.dt); wl.step_internal(scene.dt); wl.synchronize()
+    assert np.array_equal(wf.transforms(1), wl.transforms(1))
+    assert np.array_equal(wf.velocities(), wl.velocities())
+    assert wf.stats()["numFlowRecoveries"] == 1
