@@ -83,13 +83,20 @@ def main():
     label, default_settle = WORKLOADS[args.workload]
     settle = default_settle if args.settle < 0 else args.settle
     scene = scenes.by_name(args.workload)
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
 
     if world_size > 1:
         import torch.distributed as dist
         from directx_renderer_kurth_amd import parallel
-        dist.init_process_group("nccl")
-        stepper = parallel.SlabWorld(scene, device=local_rank, rank=rank, world_size=world_size)
+        # RCCL over xGMI; MI_BENCH_BACKEND=gloo (messages staged through host memory) only exists to rehearse this path with
+        # several ranks on ONE GPU, where RCCL refuses duplicate devices
+        backend = os.environ.get("MI_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend)
+        n_dev = torch.cuda.device_count()
+        if local_rank >= n_dev:
+            local_rank = local_rank % max(1, n_dev)
+            torch.cuda.set_device(local_rank)
+        stepper = parallel.SlabWorld(scene, device=local_rank, rank=rank, world_size=world_size, comm_on_cpu=(backend == "gloo"))
         barrier = dist.barrier
     else:
         dist = None
@@ -141,7 +148,7 @@ def main():
             "config": {"workload": "%s: %s, dt 1/%d s, 30 solver iterations, settled %d steps" % (args.workload, label, round(1.0 / scene.dt), settle),
                        "bodies": scene.num_bodies, "broadphase_pairs": round(mean["numBroadphaseOverlaps"]), "manifolds": round(mean["numCollisions"]),
                        "contacts": round(contacts), "colors": round(mean["numColors"], 1), "joints": round(mean["numJoints"]),
-                       "parallelism": "1 gpu" if world_size == 1 else "%d spatial slabs + ghost-body halo over RCCL" % world_size},
+                       "parallelism": "1 gpu" if world_size == 1 else "%d spatial slabs + ghost-body halo (%s)" % (world_size, "RCCL over xGMI" if os.environ.get("MI_BENCH_BACKEND", "nccl") == "nccl" else "gloo rehearsal")},
             "stage_ms": {k: round(mean[k], 4) for k in ("msCollidersBroad", "msNarrow", "msSolverSetup", "msSolve", "msIntegrate", "msTotal")},
             "roofline": {"bound": "hbm", "kernel": "k_solve_flow (contact PGS sweep, 30 iterations, dataflow)" if flow else "k_solve_color (contact PGS sweep, one launch per colour and iteration)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
