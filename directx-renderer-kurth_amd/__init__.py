@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "mi_world_create", "mi_world_destroy", "mi_last_error", "mi_add_body", "mi_add_hull_geometry", "mi_add_collider", "mi_add_static_collider",
     "mi_add_distance_constraint_local", "mi_add_distance_constraint_global", "mi_add_ball_constraint_local", "mi_add_ball_constraint_global",
     "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
-    "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_apply_force_torque", "mi_set_velocity",
+    "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_delete_all_constraints_from_body", "mi_delete_body", "mi_test_physics_interaction", "mi_apply_force_torque", "mi_set_velocity",
     "mi_set_transform", "mi_write_transforms", "mi_write_velocities", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
     "mi_get_stats", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_debug_num_pairs", "mi_debug_read_pairs",
     "mi_debug_read_world_colliders", "mi_debug_num_manifold_slots", "mi_debug_read_manifolds", "mi_debug_num_colors", "mi_debug_read_schedule",
@@ -191,6 +191,17 @@ class World:
 
     def delete_constraint(self, ctype, cid):
         self._check(self.lib.mi_delete_constraint(self.w, ctype, cid))
+
+    def delete_all_constraints_from_body(self, body):
+        self._check(self.lib.mi_delete_all_constraints_from_body(self.w, C.c_uint32(body)))
+
+    def delete_body(self, body):
+        self._check(self.lib.mi_delete_body(self.w, C.c_uint32(body)))
+
+    def test_physics_interaction(self, origin, direction, strength=1000.0):
+        """testPhysicsInteraction(scene, ray, strength) — reference physics.h:404.  Returns the pushed body's index or None."""
+        r = self.lib.mi_test_physics_interaction(self.w, _f(origin), _f(direction), C.c_float(strength))
+        return r - 1 if r > 0 else None
 
     def apply_force_torque(self, body, force, torque=(0, 0, 0)):
         self._check(self.lib.mi_apply_force_torque(self.w, body, _f(force), _f(torque)))

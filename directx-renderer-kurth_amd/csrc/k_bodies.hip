@@ -261,3 +261,14 @@ void launch_lerp_pose(World& w, float t)
 	if (!w.nb) return;
 	hipLaunchKernelGGL(k_lerp_pose, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, t, w.pose0.p, w.pose.p, w.poseLerp.p);
 }
+
+// simMask &= aliveMask (bodies deleted with mi_delete_body stay switched off under any caller-provided simulate mask)
+__global__ void __launch_bounds__(256) k_and_mask(u32 nb, uint8_t* __restrict__ simMask, const uint8_t* __restrict__ aliveMask)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nb && !aliveMask[i]) simMask[i] = 0;
+}
+void launch_and_mask(World& w)
+{
+	if (w.nb) hipLaunchKernelGGL(k_and_mask, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, w.simMask.p, w.aliveMask.p);
+}

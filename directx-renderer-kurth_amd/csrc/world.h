@@ -93,7 +93,7 @@ struct World
 	int lastError = 0; std::string lastErrorText;
 
 	// ---- host mirrors (add API) ----
-	struct HBody { float pos[3], rot[4]; float localCOG[3], invMass, invInertia[9]; float gravityFactor, linDamp, angDamp; float v[3], w[3], force[3], torque[3]; std::vector<u32> colliders; };
+	struct HBody { float pos[3], rot[4]; float localCOG[3], invMass, invInertia[9]; float gravityFactor, linDamp, angDamp; float v[3], w[3], force[3], torque[3]; std::vector<u32> colliders; bool removed = false; };
 	struct HCollider { float shape[10]; float restitution, friction, density; u32 type, body; float spos[3], srot[4]; };
 	std::vector<HBody> bodies;
 	std::vector<HCollider> colliders;
@@ -110,6 +110,7 @@ struct World
 	DevBuf<ColliderRec> colLocal, colWorld;
 	DevBuf<float4> colStaticPose, aabbMin, aabbMax;
 	DevBuf<float4> hullVerts, hullInfo;   // all hull vertices (xyz); per geometry {aabbMin.xyz, firstVertex}, {aabbMax.xyz, vertexCount}
+	DevBuf<uint8_t> aliveMask;            // per body: 0 = deleted (mi_delete_body); ANDed into every simulate mask handed in
 	DevBuf<uint8_t> simMask;              // per body: 1 = simulated here (owned or ghost), 0 = lives on another GPU's slab
 	// broadphase
 	DevBuf<u32> hashKey, hashKeySorted, sortIdx, sortIdxSorted, cellStart, cellEnd, largeFlag, largeScan, largeList, pairCount, pairOffset;
@@ -190,6 +191,7 @@ void flow_choose_regions(World& w);
 void launch_integrate_velocities(World& w, float dt);
 void launch_joint_init(World& w, float dt);
 void launch_joint_solve_iteration(World& w);
+void launch_and_mask(World& w);
 void launch_copy_pose0(World& w);
 void launch_lerp_pose(World& w, float t);
 size_t primitives_temp_bytes(size_t maxItems);

@@ -326,8 +326,14 @@ void World::upload()
 	pose.ensure(2 * nb1, stream); pose0.ensure(2 * nb1, stream); poseLerp.ensure(2 * nb1, stream); vel.ensure(2 * nb1, stream);
 	bprops.ensure(5 * nb1, stream); force.ensure(2 * nb1, stream); cog.ensure(nb1, stream); invIw.ensure(3 * nb1, stream);
 	bodyMask.ensure(nb1, stream); claim.ensure(2 * nb1, stream);
-	simMask.ensure(nb1, stream);
-	MI_CHECK(hipMemsetAsync(simMask.p, 1, nb1, stream));
+	simMask.ensure(nb1, stream); aliveMask.ensure(nb1, stream);
+	{
+		std::vector<uint8_t> alive(nb1, 1);
+		for (u32 i = 0; i < newNb; ++i) if (bodies[i].removed) alive[i] = 0;
+		MI_CHECK(hipMemcpyAsync(aliveMask.p, alive.data(), nb1, hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipMemcpyAsync(simMask.p, alive.data(), nb1, hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipStreamSynchronize(stream)); // `alive` goes out of scope
+	}
 	size_t ncap = std::max<size_t>(nc, 1);
 	colLocal.ensure(ncap, stream); colWorld.ensure(ncap, stream); colStaticPose.ensure(2 * ncap, stream); aabbMin.ensure(ncap, stream); aabbMax.ensure(ncap, stream);
 	hashKey.ensure(ncap, stream); hashKeySorted.ensure(ncap, stream); sortIdx.ensure(ncap, stream); sortIdxSorted.ensure(ncap, stream);
@@ -892,6 +898,196 @@ int mi_delete_all_constraints(mi_world* world)
 	return MI_OK;
 }
 
+// deleteAllConstraintsFromEntity (physics.h:264, physics.cpp:516-538): every joint that references the body
+int mi_delete_all_constraints_from_body(mi_world* world, uint32_t body)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
+	for (auto& js : W->joints)
+		for (u32 i = 0; i < js.count(); ++i)
+			if (js.alive[i] && (js.a[i] == body || js.b[i] == body)) { js.alive[i] = 0; W->jointsDirty = true; }
+	return MI_OK;
+}
+
+// Entity deletion (scene.deleteEntity -> the rigid body, its colliders and its constraints go away; collision_broad.cpp:42-75
+// removes the colliders from the sweep).  Body and collider indices are add-order positions and stay valid: the body is switched
+// off (no AABBs, no integration — the mechanism of the spatial slabs), its joints are deleted.
+int mi_delete_body(mi_world* world, uint32_t body)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
+	W->resolvePendingFlow();
+	int e = mi_delete_all_constraints_from_body(world, body);
+	if (e) return e;
+	{ World::HBody& hb = W->bodies[body]; hb.removed = true; hb.invMass = 0.f; for (int i = 0; i < 3; ++i) { hb.v[i] = 0.f; hb.w[i] = 0.f; } }
+	if (W->stateOnDevice && !W->topologyDirty && body < W->nb)
+	{
+		uint8_t zero = 0;
+		float4 still[2] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f) }; // gone: no velocity, no mass
+		MI_CHECK(hipMemcpyAsync(W->vel.p + 2 * body, still, sizeof(still), hipMemcpyHostToDevice, W->stream));
+		MI_CHECK(hipMemcpyAsync(W->simMask.p + body, &zero, 1, hipMemcpyHostToDevice, W->stream));
+		MI_CHECK(hipMemcpyAsync(W->aliveMask.p + body, &zero, 1, hipMemcpyHostToDevice, W->stream));
+		MI_CHECK(hipStreamSynchronize(W->stream));
+	}
+	return W->lastError;
+}
+
+// ---- testPhysicsInteraction (physics.h:404, physics.cpp:556-628): ray vs every collider of every rigid body, in the body's frame;
+// the closest hit gets force = direction * strength at the hit point.  Host code, like the reference's (an editor interaction).
+// Ray tests: bounding_volumes.cpp:197-394, 677-705; pointInTriangle: math.cpp:1273-1290.
+struct HRay { V3 origin, direction; };
+static bool rayPlane(const HRay& r, V3 normal, float d, float& outT)
+{
+	float ndotd = dot(r.direction, normal);
+	if (fabsf(ndotd) < 1e-6f) return false;
+	outT = -(dot(r.origin, normal) + d) / ndotd;
+	return true;
+}
+static bool rayAABB(const HRay& r, V3 lo, V3 hi, float& outT)
+{
+	V3 invDir = v3(1.f / r.direction.x, 1.f / r.direction.y, 1.f / r.direction.z);
+	float tx1 = (lo.x - r.origin.x) * invDir.x, tx2 = (hi.x - r.origin.x) * invDir.x;
+	outT = fminf(tx1, tx2);
+	float tmax = fmaxf(tx1, tx2);
+	float ty1 = (lo.y - r.origin.y) * invDir.y, ty2 = (hi.y - r.origin.y) * invDir.y;
+	outT = fmaxf(outT, fminf(ty1, ty2)); tmax = fminf(tmax, fmaxf(ty1, ty2));
+	float tz1 = (lo.z - r.origin.z) * invDir.z, tz2 = (hi.z - r.origin.z) * invDir.z;
+	outT = fmaxf(outT, fminf(tz1, tz2)); tmax = fminf(tmax, fmaxf(tz1, tz2));
+	return tmax >= outT && outT > 0.f;
+}
+static bool raySphere(const HRay& r, V3 center, float radius, float& outT)
+{
+	V3 m = r.origin - center;
+	float b = dot(m, r.direction), c = dot(m, m) - radius * radius;
+	if (c > 0.f && b > 0.f) return false;
+	float discr = b * b - c;
+	if (discr < 0.f) return false;
+	outT = -b - sqrtf(discr);
+	if (outT < 0.f) outT = 0.f;
+	return true;
+}
+static bool rayDisk(const HRay& r, V3 pos, V3 normal, float radius, float& outT)
+{
+	if (rayPlane(r, normal, -dot(normal, pos), outT)) return length(r.origin + outT * r.direction - pos) <= radius;
+	return false;
+}
+static bool rayCylinder(const HRay& r, V3 pa, V3 pb, float radius, float& outT)
+{
+	V3 axis = pb - pa;
+	float height = length(axis);
+	Q4 q = rotateFromTo(axis, v3(0.f, 1.f, 0.f));
+	V3 o = q * (r.origin - pa), d = q * r.direction;
+	const float epsilon = 1e-6f;
+	float y = -1.f;
+	if (o.x * o.x + o.z * o.z > radius * radius)
+	{
+		float a = d.x * d.x + d.z * d.z, b = d.x * o.x + d.z * o.z, c = o.x * o.x + o.z * o.z - radius * radius;
+		float delta = b * b - a * c;
+		if (delta < epsilon) return false;
+		outT = (-b - sqrtf(delta)) / a;
+		if (outT <= epsilon) return false;
+		y = o.y + outT * d.y;
+	}
+	if (y > height + epsilon || y < -epsilon)
+	{
+		HRay lr{ o, d };
+		float dist;
+		if (d.y < 0.f && rayDisk(lr, v3(0.f, height, 0.f), v3(0.f, 1.f, 0.f), radius, dist)) outT = dist;
+		if (d.y > 0.f && rayDisk(lr, v3(0.f, 0.f, 0.f), v3(0.f, -1.f, 0.f), radius, dist)) outT = dist;
+		y = o.y + outT * d.y;
+	}
+	return y > -epsilon && y < height + epsilon;
+}
+static bool rayCapsule(const HRay& r, V3 pa, V3 pb, float radius, float& outT)
+{
+	outT = MI_FLT_MAX;
+	float t; bool result = false;
+	if (rayCylinder(r, pa, pb, radius, t)) { outT = t; result = true; }
+	if (raySphere(r, pa, radius, t)) { outT = fminf(outT, t); result = true; }
+	if (raySphere(r, pb, radius, t)) { outT = fminf(outT, t); result = true; }
+	return result;
+}
+static bool pointInTriangleH(V3 point, V3 a, V3 b, V3 c)
+{
+	V3 e10 = b - a, e20 = c - a;
+	float aa = dot(e10, e10), bb = dot(e10, e20), cc = dot(e20, e20);
+	float ac_bb = (aa * cc) - (bb * bb);
+	V3 vp = point - a;
+	float d = dot(vp, e10), e = dot(vp, e20);
+	float x = (d * cc) - (e * bb), y = (e * aa) - (d * bb), z = x + y - ac_bb;
+	u32 ux, uy, uz; memcpy(&ux, &x, 4); memcpy(&uy, &y, 4); memcpy(&uz, &z, 4);
+	return ((uz & ~(ux | uy)) & 0x80000000u) != 0;
+}
+static bool rayTriangle(const HRay& r, V3 a, V3 b, V3 c, float& outT)
+{
+	V3 normal = noz(cross(b - a, c - a));
+	float d = -dot(normal, a);
+	float nDotR = dot(r.direction, normal);
+	if (fabsf(nDotR) <= 1e-6f) return false;
+	outT = -(dot(r.origin, normal) + d) / nDotR;
+	V3 q = r.origin + outT * r.direction;
+	return outT >= 0.f && pointInTriangleH(q, a, b, c);
+}
+
+int mi_test_physics_interaction(mi_world* world, const float origin[3], const float direction[3], float strength)
+{
+	CHECK_WORLD(0);
+	W->upload();
+	if (W->stateOnDevice) W->downloadState(); // physics_transform1 of every body
+	HRay r{ v3(origin[0], origin[1], origin[2]), v3(direction[0], direction[1], direction[2]) };
+	float minT = MI_FLT_MAX; int minBody = -1; V3 force = v3s(0.f), torque = v3s(0.f);
+	for (const World::HCollider& c : W->colliders)
+	{
+		if (c.body == MI_STATIC_BODY || W->bodies[c.body].removed) continue;
+		const World::HBody& rb = W->bodies[c.body];
+		Q4 rot = q4(rb.rot[0], rb.rot[1], rb.rot[2], rb.rot[3]); V3 pos = v3(rb.pos[0], rb.pos[1], rb.pos[2]);
+		HRay lr{ conjugate(rot) * (r.origin - pos), conjugate(rot) * r.direction };
+		const float* s = c.shape;
+		float t = 0.f; bool hit = false;
+		switch (c.type)
+		{
+			case MI_SPHERE: hit = raySphere(lr, v3(s[0], s[1], s[2]), s[3], t); break;
+			case MI_CAPSULE: hit = rayCapsule(lr, v3(s[0], s[1], s[2]), v3(s[3], s[4], s[5]), s[6], t); break;
+			case MI_CYLINDER: hit = rayCylinder(lr, v3(s[0], s[1], s[2]), v3(s[3], s[4], s[5]), s[6], t); break;
+			case MI_AABB: hit = rayAABB(lr, v3(s[0], s[1], s[2]), v3(s[3], s[4], s[5]), t); break;
+			case MI_OBB:
+			{
+				Q4 q = q4(s[0], s[1], s[2], s[3]); V3 ce = v3(s[4], s[5], s[6]), ra = v3(s[7], s[8], s[9]);
+				HRay br{ conjugate(q) * (lr.origin - ce), conjugate(q) * lr.direction };
+				hit = rayAABB(br, v3s(0.f) - ra, ra, t);
+			} break;
+			case MI_HULL:
+			{
+				Q4 q = q4(s[0], s[1], s[2], s[3]); V3 hp = v3(s[4], s[5], s[6]);
+				const World::HHull& g = W->hulls[(u32)s[7]];
+				HRay hr{ conjugate(q) * (lr.origin - hp), conjugate(q) * lr.direction };
+				float best = MI_FLT_MAX;
+				for (size_t f = 0; f + 2 < g.triangles.size(); f += 3)
+				{
+					const float* pa = &g.vertices[3 * g.triangles[f]]; const float* pb = &g.vertices[3 * g.triangles[f + 1]]; const float* pc = &g.vertices[3 * g.triangles[f + 2]];
+					float tt;
+					if (rayTriangle(hr, v3(pa[0], pa[1], pa[2]), v3(pb[0], pb[1], pb[2]), v3(pc[0], pc[1], pc[2]), tt) && tt < best) { best = tt; hit = true; }
+				}
+				t = best;
+			} break;
+			default: break;
+		}
+		if (hit && t < minT)
+		{
+			minT = t; minBody = (int)c.body;
+			V3 localHit = lr.origin + t * lr.direction;
+			V3 globalHit = rot * localHit + pos;                                   // transformPosition (scale 1)
+			V3 cogPosition = pos + rot * v3(rb.localCOG[0], rb.localCOG[1], rb.localCOG[2]); // getGlobalCOGPosition (rigid_body.cpp:83-87)
+			force = r.direction * strength;
+			torque = cross(globalHit - cogPosition, force);
+		}
+	}
+	if (minBody < 0) return 0;
+	float f[3] = { force.x, force.y, force.z }, tq[3] = { torque.x, torque.y, torque.z };
+	if (mi_apply_force_torque(world, (uint32_t)minBody, f, tq)) return 0;
+	return 1 + minBody; // the body that was pushed, plus one
+}
+
 int mi_apply_force_torque(mi_world* world, uint32_t body, const float f[3], const float t[3])
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
@@ -1067,7 +1263,11 @@ int mi_state_from_device_buffers(mi_world* world, const void* dPose, const void*
 	if (!W->nb) return W->lastError;
 	if (dPose) MI_CHECK(hipMemcpyAsync(W->pose.p, dPose, sizeof(float4) * 2 * W->nb, hipMemcpyDeviceToDevice, W->stream));
 	if (dVel) MI_CHECK(hipMemcpyAsync(W->vel.p, dVel, sizeof(float4) * 2 * W->nb, hipMemcpyDeviceToDevice, W->stream));
-	if (dMask) MI_CHECK(hipMemcpyAsync(W->simMask.p, dMask, W->nb, hipMemcpyDeviceToDevice, W->stream));
+	if (dMask)
+	{
+		MI_CHECK(hipMemcpyAsync(W->simMask.p, dMask, W->nb, hipMemcpyDeviceToDevice, W->stream));
+		launch_and_mask(*W); // deleted bodies stay off whatever the caller's mask says
+	}
 	return W->lastError;
 }
 

@@ -156,6 +156,9 @@ namespace mi
 			return checkId(mi_add_hull_geometry(world, &vertices[0].x, (uint32_t)vertices.size(), triangles.data(), (uint32_t)(triangles.size() / 3)), "allocateBoundingHullGeometry");
 		}
 
+		// scene.deleteEntity for an entity with a rigid body: body, colliders and constraints leave the simulation
+		void deleteEntity(uint32_t entityIndex) { if (entities[entityIndex].body != MI_STATIC_BODY) check(mi_delete_body(world, entities[entityIndex].body), "deleteEntity"); }
+
 		scene_entity createEntity(const char* /*name*/ = nullptr) { entities.emplace_back(); return scene_entity{ this, (uint32_t)entities.size() - 1 }; }
 
 		void check(int status, const char* what) const { if (status != MI_OK) throw physics_error(std::string(what) + ": " + mi_last_error(world)); }
@@ -263,6 +266,11 @@ namespace mi
 	template <typename T> inline constraint_ref<T> getConstraint(game_scene& scene, constraint_handle<T> handle) { return constraint_ref<T>(scene, handle.id); }
 	template <typename T> inline void deleteConstraint(game_scene& scene, constraint_handle<T> handle) { scene.check(mi_delete_constraint(scene.world, constraint_type_of<T>::value, handle.id), "deleteConstraint"); }
 	inline void deleteAllConstraints(game_scene& scene) { scene.check(mi_delete_all_constraints(scene.world), "deleteAllConstraints"); }
+
+	inline void deleteAllConstraintsFromEntity(scene_entity& entity) { entity.scene->check(mi_delete_all_constraints_from_body(entity.scene->world, entity.body()), "deleteAllConstraintsFromEntity"); } // physics.h:264
+	struct ray { vec3 origin, direction; };
+	// void testPhysicsInteraction(game_scene&, ray, float strength = 1000.f), physics.h:404
+	inline void testPhysicsInteraction(game_scene& scene, ray r, float strength = 1000.f) { scene.flushStaticColliders(); mi_test_physics_interaction(scene.world, &r.origin.x, &r.direction.x, strength); }
 
 	// ---- void physicsStep(game_scene&, memory_arena&, float& timer, const physics_settings&, float dt), physics.h:405
 	inline void physicsStep(game_scene& scene, memory_arena& /*arena*/, float& timer, const physics_settings& settings, float dt)

@@ -106,7 +106,15 @@ int mi_constraint_get(mi_world* w, uint32_t type, uint32_t id, void* pod);
 int mi_constraint_set(mi_world* w, uint32_t type, uint32_t id, const void* pod);
 int mi_delete_constraint(mi_world* w, uint32_t type, uint32_t id);    /* deleteConstraint, physics.h:257-262 */
 int mi_delete_all_constraints(mi_world* w);                           /* deleteAllConstraints, physics.h:255 */
+int mi_delete_all_constraints_from_body(mi_world* w, uint32_t body);  /* deleteAllConstraintsFromEntity, physics.h:264 */
+/* Deleting the entity of a rigid body (scene.deleteEntity: body, colliders and constraints go away; the colliders leave the sweep,
+ * collision_broad.cpp:42-75).  Indices are add-order positions and stay valid; the body is switched off for good. */
+int mi_delete_body(mi_world* w, uint32_t body);
 
+/* void testPhysicsInteraction(game_scene&, ray, float strength = 1000.f): physics.h:404, physics.cpp:556-628 — the closest rigid-body
+ * collider hit by the ray gets force = direction * strength at the hit point.  Returns 1 + the index of the body that was
+ * pushed, 0 when the ray hits nothing (this one function does not return a status code). */
+int mi_test_physics_interaction(mi_world* w, const float origin[3], const float direction[3], float strength);
 /* rigid_body_component::{forceAccumulator,torqueAccumulator} += (testPhysicsInteraction applies them the same way, physics.cpp:624-628). */
 int mi_apply_force_torque(mi_world* w, uint32_t body, const float force[3], const float torque[3]);
 int mi_set_velocity(mi_world* w, uint32_t body, const float linear[3], const float angular[3]);

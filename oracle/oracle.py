@@ -59,7 +59,7 @@ def _lib(avx2=False):
                      "orc_add_fixed_constraint_global", "orc_add_hinge_constraint_global", "orc_add_cone_twist_constraint_global",
                      "orc_add_slider_constraint_global", "orc_num_bodies", "orc_num_colliders", "orc_num_pairs", "orc_num_contacts",
                      "orc_num_collisions", "orc_sorting_axis_used", "orc_sorting_axis_next", "orc_num_contact_slots",
-                     "orc_narrowphase_ordered", "orc_schedule", "orc_read_slot_counts", "orc_add_hull_geometry"):
+                     "orc_narrowphase_ordered", "orc_schedule", "orc_read_slot_counts", "orc_add_hull_geometry", "orc_test_physics_interaction"):
             getattr(lib, name).restype = C.c_uint32
         _libs[key] = lib
     return _libs[key]
@@ -138,6 +138,13 @@ class OracleWorld:
     def constraint_set(self, ctype, cid, buf):
         buf = np.ascontiguousarray(buf, np.uint8)
         assert self.lib.orc_constraint_set(self.w, ctype, cid, _p(buf)) == 0
+
+    def delete_body(self, body):
+        assert self.lib.orc_delete_body(self.w, C.c_uint32(body)) == 0
+
+    def test_physics_interaction(self, origin, direction, strength=1000.0):
+        r = self.lib.orc_test_physics_interaction(self.w, _f(origin), _f(direction), C.c_float(strength))
+        return r - 1 if r > 0 else None
 
     def apply_force_torque(self, body, force, torque=(0, 0, 0)):
         assert self.lib.orc_apply_force_torque(self.w, body, _f(force), _f(torque)) == 0

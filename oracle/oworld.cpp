@@ -26,6 +26,7 @@ struct body
 	vec3 linearVelocity, angularVelocity, forceAccumulator, torqueAccumulator;
 	trs transform, transform0, transform1;
 	std::vector<u32> colliders; // add order; the reference's intrusive list walks it newest-first (scene.h:56-58)
+	bool removed = false;       // entity deleted: the body and its colliders no longer take part (indices stay valid)
 };
 
 struct collider
@@ -269,6 +270,13 @@ static void getWorldSpaceColliders(world& w)
 		col = c.local;
 		if (c.parent != STATIC_BODY) { col.objectIndex = c.parent; col.objectType = physics_object_type_rigid_body; }
 		else { col.objectIndex = dummyRigidBodyIndex; col.objectType = physics_object_type_static_collider; }
+		if (c.parent != STATIC_BODY && w.bodies[c.parent].removed)
+		{
+			// deleted entity: the reference takes the collider out of the sweep (collision_broad.cpp:42-75); keeping collider indices
+			// stable, it is parked where it can overlap nothing instead
+			bb = bounding_box::fromCenterRadius(vec3(1.0e7f + 16.f * (float)i, -1.0e7f, 0.f), 0.25f);
+			continue;
+		}
 		switch (c.local.type)
 		{
 			case collider_type_sphere:
@@ -830,6 +838,170 @@ static void* constraintPtr(world* w, u32 type, u32 id, u32* size)
 }
 int orc_constraint_get(world* w, u32 type, u32 id, void* pod) { u32 s; void* p = constraintPtr(w, type, id, &s); if (!p) return 1; memcpy(pod, p, s); return 0; }
 int orc_constraint_set(world* w, u32 type, u32 id, const void* pod) { u32 s; void* p = constraintPtr(w, type, id, &s); if (!p) return 1; memcpy(p, pod, s); return 0; }
+
+int orc_delete_body(world* w, u32 b)
+{
+	if (b >= w->bodies.size()) return 1;
+	body& rb = w->bodies[b];
+	rb.removed = true; rb.invMass = 0.f; rb.invInertia = mat3::zero(); rb.gravityFactor = 0.f;
+	rb.linearVelocity = rb.angularVelocity = rb.forceAccumulator = rb.torqueAccumulator = vec3(0.f);
+	return 0;
+}
+
+// ---- testPhysicsInteraction — physics.cpp:556-628; ray tests bounding_volumes.cpp:197-394, 677-705; pointInTriangle math.cpp:1273-1290
+struct ray { vec3 origin, direction; };
+static bool intersectPlane(const ray& r, vec3 normal, float d, float& outT)
+{
+	float ndotd = dot(r.direction, normal);
+	if (fabsf(ndotd) < 1e-6f) { return false; }
+	outT = -(dot(r.origin, normal) + d) / ndotd;
+	return true;
+}
+static bool intersectAABB(const ray& r, const bounding_box& a, float& outT)
+{
+	vec3 invDir = vec3(1.f / r.direction.x, 1.f / r.direction.y, 1.f / r.direction.z);
+	float tx1 = (a.minCorner.x - r.origin.x) * invDir.x, tx2 = (a.maxCorner.x - r.origin.x) * invDir.x;
+	outT = std::min(tx1, tx2);
+	float tmax = std::max(tx1, tx2);
+	float ty1 = (a.minCorner.y - r.origin.y) * invDir.y, ty2 = (a.maxCorner.y - r.origin.y) * invDir.y;
+	outT = std::max(outT, std::min(ty1, ty2)); tmax = std::min(tmax, std::max(ty1, ty2));
+	float tz1 = (a.minCorner.z - r.origin.z) * invDir.z, tz2 = (a.maxCorner.z - r.origin.z) * invDir.z;
+	outT = std::max(outT, std::min(tz1, tz2)); tmax = std::min(tmax, std::max(tz1, tz2));
+	return tmax >= outT && outT > 0.f;
+}
+static bool intersectSphere(const ray& r, vec3 center, float radius, float& outT)
+{
+	vec3 m = r.origin - center;
+	float b = dot(m, r.direction), c = dot(m, m) - radius * radius;
+	if (c > 0.f && b > 0.f) { return false; }
+	float discr = b * b - c;
+	if (discr < 0.f) { return false; }
+	outT = -b - sqrtf(discr);
+	if (outT < 0.f) { outT = 0.f; }
+	return true;
+}
+static bool intersectDisk(const ray& r, vec3 pos, vec3 normal, float radius, float& outT)
+{
+	if (intersectPlane(r, normal, -dot(normal, pos), outT)) { return length(r.origin + outT * r.direction - pos) <= radius; }
+	return false;
+}
+static bool intersectCylinder(const ray& r, const bounding_cylinder& cylinder, float& outT)
+{
+	vec3 d = r.direction, o = r.origin;
+	vec3 axis = cylinder.positionB - cylinder.positionA;
+	float height = length(axis);
+	quat q = rotateFromTo(axis, vec3(0.f, 1.f, 0.f));
+	o = q * (o - cylinder.positionA);
+	d = q * d;
+	float epsilon = 1e-6f;
+	float y = -1.f;
+	if (o.x * o.x + o.z * o.z > cylinder.radius * cylinder.radius)
+	{
+		float a = d.x * d.x + d.z * d.z, b = d.x * o.x + d.z * o.z, c = o.x * o.x + o.z * o.z - cylinder.radius * cylinder.radius;
+		float delta = b * b - a * c;
+		if (delta < epsilon) { return false; }
+		outT = (-b - sqrtf(delta)) / a;
+		if (outT <= epsilon) { return false; }
+		y = o.y + outT * d.y;
+	}
+	if (y > height + epsilon || y < -epsilon)
+	{
+		ray localRay = { o, d };
+		float dist;
+		bool b1 = d.y < 0.f && intersectDisk(localRay, vec3(0.f, height, 0.f), vec3(0.f, 1.f, 0.f), cylinder.radius, dist);
+		if (b1) { outT = dist; }
+		bool b2 = d.y > 0.f && intersectDisk(localRay, vec3(0.f, 0.f, 0.f), vec3(0.f, -1.f, 0.f), cylinder.radius, dist);
+		if (b2) { outT = dist; }
+		y = o.y + outT * d.y;
+	}
+	return y > -epsilon && y < height + epsilon;
+}
+static bool intersectCapsule(const ray& r, const bounding_capsule& capsule, float& outT)
+{
+	outT = FLT_MAX;
+	float t; bool result = false;
+	if (intersectCylinder(r, bounding_cylinder{ capsule.positionA, capsule.positionB, capsule.radius }, t)) { outT = t; result = true; }
+	if (intersectSphere(r, capsule.positionA, capsule.radius, t)) { outT = std::min(outT, t); result = true; }
+	if (intersectSphere(r, capsule.positionB, capsule.radius, t)) { outT = std::min(outT, t); result = true; }
+	return result;
+}
+static bool pointInTriangle(vec3 point, vec3 triA, vec3 triB, vec3 triC)
+{
+	vec3 e10 = triB - triA, e20 = triC - triA;
+	float a = dot(e10, e10), b = dot(e10, e20), c = dot(e20, e20);
+	float ac_bb = (a * c) - (b * b);
+	vec3 vp = point - triA;
+	float d = dot(vp, e10), e = dot(vp, e20);
+	float x = (d * c) - (e * b), y = (e * a) - (d * b), z = x + y - ac_bb;
+	u32 ux, uy, uz; memcpy(&ux, &x, 4); memcpy(&uy, &y, 4); memcpy(&uz, &z, 4);
+	return ((uz & ~(ux | uy)) & 0x80000000u) != 0;
+}
+static bool intersectTriangle(const ray& r, vec3 a, vec3 b, vec3 c, float& outT)
+{
+	vec3 normal = noz(cross(b - a, c - a));
+	float d = -dot(normal, a);
+	float nDotR = dot(r.direction, normal);
+	if (fabsf(nDotR) <= 1e-6f) { return false; }
+	outT = -(dot(r.origin, normal) + d) / nDotR;
+	vec3 q = r.origin + outT * r.direction;
+	return outT >= 0.f && pointInTriangle(q, a, b, c);
+}
+// returns 1 + the index of the pushed body, 0 if nothing was hit
+u32 orc_test_physics_interaction(world* w, const float* origin, const float* direction, float strength)
+{
+	ray r = { v3(origin), v3(direction) };
+	float minT = FLT_MAX; int minRB = -1;
+	vec3 force(0.f), torque(0.f);
+	for (const collider& col : w->colliders)
+	{
+		if (col.parent == STATIC_BODY || w->bodies[col.parent].removed) { continue; }
+		const body& rb = w->bodies[col.parent];
+		const trs& transform = rb.transform1;
+		ray localR = { conjugate(transform.rotation) * (r.origin - transform.position), conjugate(transform.rotation) * r.direction };
+		float t = 0.f; bool hit = false;
+		const collider_union& c = col.local;
+		switch (c.type)
+		{
+			case collider_type_sphere: { bounding_sphere s = c.sphere(); hit = intersectSphere(localR, s.center, s.radius, t); } break;
+			case collider_type_capsule: hit = intersectCapsule(localR, c.capsule(), t); break;
+			case collider_type_cylinder: hit = intersectCylinder(localR, c.cylinder(), t); break;
+			case collider_type_aabb: hit = intersectAABB(localR, c.aabb(), t); break;
+			case collider_type_obb:
+			{
+				bounding_oriented_box a = c.obb();
+				ray lr = { conjugate(a.rotation) * (localR.origin - a.center), conjugate(a.rotation) * localR.direction };
+				hit = intersectAABB(lr, bounding_box::fromCenterRadius(vec3(0.f), a.radius), t);
+			} break;
+			case collider_type_hull:
+			{
+				bounding_hull h = c.hull();
+				const bounding_hull_geometry& g = w->hullGeometries[h.geometryIndex];
+				ray lr = { conjugate(h.rotation) * (localR.origin - h.position), conjugate(h.rotation) * localR.direction };
+				float best = FLT_MAX;
+				for (const bounding_hull_face& f : g.faces)
+				{
+					float tt;
+					if (intersectTriangle(lr, g.vertices[f.a], g.vertices[f.b], g.vertices[f.c], tt) && tt < best) { best = tt; hit = true; }
+				}
+				t = best;
+			} break;
+			default: break;
+		}
+		if (hit && t < minT)
+		{
+			minT = t; minRB = (int)col.parent;
+			vec3 localHit = localR.origin + t * localR.direction;
+			vec3 globalHit = transformPosition(transform, localHit);
+			vec3 cogPosition = transform.position + transform.rotation * rb.localCOGPosition; // getGlobalCOGPosition (rigid_body.cpp:83-87)
+			force = r.direction * strength;
+			torque = cross(globalHit - cogPosition, force);
+		}
+	}
+	if (minRB < 0) { return 0; }
+	w->bodies[minRB].torqueAccumulator += torque;
+	w->bodies[minRB].forceAccumulator += force;
+	return 1u + (u32)minRB;
+}
 
 int orc_apply_force_torque(world* w, u32 b, const float* f, const float* t)
 {

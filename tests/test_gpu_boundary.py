@@ -1,0 +1,75 @@
+"""The remaining entry points of the drop-in boundary: testPhysicsInteraction, entity deletion,
+deleteAllConstraintsFromEntity — the device world against the oracle in follow mode."""
+import numpy as np
+import pytest
+
+from parity_util import follow_step
+
+pytestmark = pytest.mark.gpu
+
+
+def _worlds(mi, oracle, scene):
+    return scene.instantiate(mi.World()), scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_CUSTOM))
+
+
+def test_physics_interaction_matches_oracle(mi, oracle):
+    """testPhysicsInteraction (physics.cpp:556-628): same body hit by every ray (all six collider types are in the scene), and the
+    push (force at the hit point -> force + torque accumulators) gives the same velocities after the next step."""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name("shapes_hull")
+    g, o = _worlds(mi, oracle, scene)
+    for _ in range(150):
+        r = follow_step(g, o, scene.dt, 30, {})
+        assert r["vel_err"] <= 1e-4 * max(1.0, r["vel_scale"])
+    rng = np.random.default_rng(7)
+    hits = set()
+    for k in range(24):
+        origin = np.array([rng.uniform(-12, 12), rng.uniform(0.3, 4.0), rng.uniform(-12, 12)], np.float32)
+        target = np.array([rng.uniform(-4, 4), rng.uniform(0.2, 2.0), rng.uniform(-4, 4)], np.float32)
+        d = target - origin; d = (d / np.linalg.norm(d)).astype(np.float32)
+        hg = g.test_physics_interaction(origin, d, 500.0)
+        ho = o.test_physics_interaction(origin, d, 500.0)
+        assert hg == ho, "ray %d: device pushed body %s, oracle %s" % (k, hg, ho)
+        if hg is not None:
+            hits.add(hg)
+        r = follow_step(g, o, scene.dt, 30, {})
+        assert r["vel_err"] <= 1e-4 * max(1.0, r["vel_scale"]), "ray %d" % k
+    assert len(hits) >= 6
+    assert g.test_physics_interaction((0, 50, 0), (0, 1, 0)) is None   # pointing away from everything
+
+
+def test_delete_body_matches_oracle(mi, oracle):
+    """Deleting bodies from the middle of a pile: they stop colliding and moving on both sides, everything else keeps matching."""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name("c3_small")
+    g, o = _worlds(mi, oracle, scene)
+    for _ in range(30):
+        follow_step(g, o, scene.dt, 30, {})
+    victims = [5, 400, 401, 1777, 2999]
+    frozen = g.transforms(1)[victims].copy()
+    for b in victims:
+        g.delete_body(b); o.delete_body(b)
+    for i in range(30):
+        r = follow_step(g, o, scene.dt, 30, {})
+        assert r["pairs_equal"] and r["counts_equal"], "step %d" % i
+        assert r["vel_err"] <= 1e-4 * max(1.0, r["vel_scale"]), "step %d" % i
+    assert np.array_equal(g.transforms(1)[victims], frozen)            # switched off: never integrated again
+    pairs, counts, contacts, bp = g.manifolds()
+    assert not np.isin(bp[counts > 0], victims).any()                   # and in no contact
+
+
+def test_delete_all_constraints_from_body(mi):
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name("c4_small")
+    g = scene.instantiate(mi.World())
+    g.step_internal(scene.dt)
+    before = g.stats()["numJoints"]
+    torso = 0                                                           # first body of the first ragdoll: several joints attach to it
+    attached = sum(1 for j in scene.joints if torso in (j[1], j[2]))
+    assert attached > 0
+    g.delete_all_constraints_from_body(torso)
+    g.step_internal(scene.dt)
+    assert g.stats()["numJoints"] == before - attached
+    for _ in range(60):
+        g.step_internal(scene.dt)
+    assert np.isfinite(g.transforms(1)).all()
