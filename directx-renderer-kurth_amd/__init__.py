@@ -73,7 +73,22 @@ def build(force=False):
     if force:
         subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j6"], stdout=subprocess.DEVNULL)
+    build_locomotion()
     return _LIB_PATH
+
+
+LOCOMOTION_LIB_PATH = os.path.join(_HERE, "libmi_locomotion.so")
+LOCOMOTION_SYMBOLS = ["getPhysicsStateSize", "getPhysicsActionSize", "getPhysicsRanges", "resetPhysics", "updatePhysics", "setPhysicsSeed"]
+
+
+def build_locomotion():
+    """Host-side C++ over the C-ABI: the reference's ragdoll RL environment (learned_locomotion.cpp:395-489) as libmi_locomotion.so."""
+    src = os.path.join(_HERE, "host", "locomotion_env.cpp")
+    if os.path.exists(LOCOMOTION_LIB_PATH) and os.path.getmtime(LOCOMOTION_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(_LIB_PATH)):
+        return LOCOMOTION_LIB_PATH
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(os.path.dirname(_HERE), "include"), src,
+                           "-L" + _HERE, "-lmi_physics", "-Wl,-rpath,$ORIGIN", "-o", LOCOMOTION_LIB_PATH])
+    return LOCOMOTION_LIB_PATH
 
 
 _lib = None
