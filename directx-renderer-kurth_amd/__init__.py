@@ -57,7 +57,7 @@ class Stats(C.Structure):
 
 
 EXPORTED_SYMBOLS = [
-    "mi_world_create", "mi_world_destroy", "mi_last_error", "mi_add_body", "mi_add_hull_geometry", "mi_add_collider", "mi_add_static_collider",
+    "mi_world_create", "mi_world_destroy", "mi_last_error", "mi_snapshot_size", "mi_snapshot_save", "mi_world_restore", "mi_add_body", "mi_add_hull_geometry", "mi_add_collider", "mi_add_static_collider",
     "mi_add_distance_constraint_local", "mi_add_distance_constraint_global", "mi_add_ball_constraint_local", "mi_add_ball_constraint_global",
     "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
     "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_delete_all_constraints_from_body", "mi_delete_body", "mi_test_physics_interaction", "mi_apply_force_torque", "mi_set_velocity",
@@ -102,6 +102,8 @@ def load_library():
             raise RuntimeError("libmi_physics.so is missing: run __graft_entry__.build() (hipcc) first; there is no CPU fallback")
         lib = C.CDLL(_LIB_PATH)
         lib.mi_world_create.restype = C.c_void_p
+        lib.mi_world_restore.restype = C.c_void_p
+        lib.mi_snapshot_size.restype = C.c_uint64
         lib.mi_last_error.restype = C.c_char_p
         for name in EXPORTED_SYMBOLS:
             fn = getattr(lib, name)
@@ -134,6 +136,26 @@ class World:
             raise PhysicsError("mi_world_create failed: %s" % (self.lib.mi_last_error(None) or b"").decode())
         self.w = C.c_void_p(h)
         self.timer = C.c_float(0.0)
+
+    def snapshot(self):
+        """Self-contained binary image of the world (checkpoint); World.restore(blob) continues it bit-identically."""
+        n = int(self.lib.mi_snapshot_size(self.w))
+        buf = np.zeros(n, np.uint8)
+        self._check(self.lib.mi_snapshot_save(self.w, _p(buf), C.c_uint64(n)))
+        return buf.tobytes()
+
+    @classmethod
+    def restore(cls, blob, device=-1):
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        desc = WorldDesc(device, 0, 0, 0)
+        buf = np.frombuffer(blob, np.uint8)
+        h = self.lib.mi_world_restore(C.byref(desc), _p(buf), C.c_uint64(len(buf)))
+        if not h:
+            raise PhysicsError("mi_world_restore failed: %s" % (self.lib.mi_last_error(None) or b"").decode())
+        self.w = C.c_void_p(h)
+        self.timer = C.c_float(0.0)
+        return self
 
     def close(self):
         if getattr(self, "w", None):

@@ -679,6 +679,45 @@ struct mi_world { World w; mi_world(int dev) : w(dev) {} };
 #define W (&world->w)
 #define CHECK_WORLD(ret) if (!world) return ret; g_currentWorld = W
 
+namespace
+{
+	const uint32_t SNAPSHOT_MAGIC = 0x4850494Du, SNAPSHOT_VERSION = 1;
+	struct BlobWriter
+	{
+		std::vector<uint8_t> bytes;
+		void put(const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; bytes.insert(bytes.end(), b, b + n); }
+		template <typename T> void pod(const T& v) { put(&v, sizeof(T)); }
+		template <typename T> void vec(const std::vector<T>& v) { uint64_t n = v.size(); pod(n); if (n) put(v.data(), n * sizeof(T)); }
+	};
+	struct BlobReader
+	{
+		const uint8_t* p; size_t left; bool ok = true;
+		void get(void* dst, size_t n) { if (n > left) { ok = false; return; } memcpy(dst, p, n); p += n; left -= n; }
+		template <typename T> void pod(T& v) { get(&v, sizeof(T)); }
+		template <typename T> void vec(std::vector<T>& v) { uint64_t n = 0; pod(n); if (!ok || n * sizeof(T) > left) { ok = false; return; } v.resize((size_t)n); if (n) get(v.data(), (size_t)n * sizeof(T)); }
+	};
+	struct BodyPod { float pos[3], rot[4], localCOG[3], invMass, invInertia[9], gravityFactor, linDamp, angDamp, v[3], w[3], force[3], torque[3]; uint32_t removed; };
+	void serialize(World& w, BlobWriter& out)
+	{
+		w.upload();
+		if (w.stateOnDevice) w.downloadState();
+		out.pod(SNAPSHOT_MAGIC); out.pod(SNAPSHOT_VERSION);
+		uint64_t nb = w.bodies.size(), nc = w.colliders.size(), nh = w.hulls.size();
+		out.pod(nb); out.pod(nc); out.pod(nh);
+		for (const World::HBody& b : w.bodies)
+		{
+			BodyPod p{};
+			memcpy(p.pos, b.pos, 12); memcpy(p.rot, b.rot, 16); memcpy(p.localCOG, b.localCOG, 12); p.invMass = b.invMass; memcpy(p.invInertia, b.invInertia, 36);
+			p.gravityFactor = b.gravityFactor; p.linDamp = b.linDamp; p.angDamp = b.angDamp;
+			memcpy(p.v, b.v, 12); memcpy(p.w, b.w, 12); memcpy(p.force, b.force, 12); memcpy(p.torque, b.torque, 12); p.removed = b.removed ? 1u : 0u;
+			out.pod(p); out.vec(b.colliders);
+		}
+		for (const World::HCollider& c : w.colliders) out.pod(c);
+		for (const World::HHull& h : w.hulls) { out.vec(h.vertices); out.vec(h.triangles); out.put(h.aabbMin, 12); out.put(h.aabbMax, 12); }
+		for (const JointSet& js : w.joints) { out.vec(js.pods); out.vec(js.a); out.vec(js.b); out.vec(js.alive); }
+	}
+}
+
 extern "C" {
 
 mi_world* mi_world_create(const mi_world_desc* desc)
@@ -700,6 +739,48 @@ mi_world* mi_world_create(const mi_world_desc* desc)
 	return world;
 }
 void mi_world_destroy(mi_world* world) { delete world; }
+
+// ---- snapshot / restore (row N3 of SURVEY §8f: checkpoint + resume; the engine's own scene files, serialization_yaml.cpp /
+// serialization_binary.cpp, are asset formats and stay out of scope).  The blob holds everything the add API and the steps have put
+// into the world: bodies with their current pose / velocity / accumulators and mass properties, colliders, hull geometries, joints.
+// A world restored from it continues bit-identically (tests/test_gpu_snapshot.py).  Layout: 'MIPH', version, six counts, then the
+// records in the order below, plain little-endian PODs.
+uint64_t mi_snapshot_size(mi_world* world) { CHECK_WORLD(0); BlobWriter out; serialize(*W, out); return out.bytes.size(); }
+int mi_snapshot_save(mi_world* world, void* buffer, uint64_t capacity)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	BlobWriter out; serialize(*W, out);
+	if (W->lastError) return W->lastError;
+	if (!buffer || capacity < out.bytes.size()) { W->fail(MI_ERR_CAPACITY, "mi_snapshot_save: buffer too small (ask mi_snapshot_size)"); return MI_ERR_CAPACITY; }
+	memcpy(buffer, out.bytes.data(), out.bytes.size());
+	return MI_OK;
+}
+mi_world* mi_world_restore(const mi_world_desc* desc, const void* buffer, uint64_t size)
+{
+	mi_world* world = mi_world_create(desc);
+	if (!world) return nullptr;
+	World& w = world->w;
+	BlobReader in{ (const uint8_t*)buffer, (size_t)size };
+	uint32_t magic = 0, version = 0; uint64_t nb = 0, nc = 0, nh = 0;
+	in.pod(magic); in.pod(version); in.pod(nb); in.pod(nc); in.pod(nh);
+	if (!in.ok || magic != SNAPSHOT_MAGIC || version != SNAPSHOT_VERSION) { g_createError = "mi_world_restore: not a snapshot of this library version"; delete world; return nullptr; }
+	for (uint64_t i = 0; in.ok && i < nb; ++i)
+	{
+		BodyPod p; in.pod(p);
+		World::HBody b{};
+		memcpy(b.pos, p.pos, 12); memcpy(b.rot, p.rot, 16); memcpy(b.localCOG, p.localCOG, 12); b.invMass = p.invMass; memcpy(b.invInertia, p.invInertia, 36);
+		b.gravityFactor = p.gravityFactor; b.linDamp = p.linDamp; b.angDamp = p.angDamp;
+		memcpy(b.v, p.v, 12); memcpy(b.w, p.w, 12); memcpy(b.force, p.force, 12); memcpy(b.torque, p.torque, 12); b.removed = p.removed != 0;
+		in.vec(b.colliders);
+		w.bodies.push_back(b);
+	}
+	for (uint64_t i = 0; in.ok && i < nc; ++i) { World::HCollider c; in.pod(c); w.colliders.push_back(c); }
+	for (uint64_t i = 0; in.ok && i < nh; ++i) { World::HHull h; in.vec(h.vertices); in.vec(h.triangles); in.get(h.aabbMin, 12); in.get(h.aabbMax, 12); w.hulls.push_back(h); }
+	for (JointSet& js : w.joints) { in.vec(js.pods); in.vec(js.a); in.vec(js.b); in.vec(js.alive); }
+	if (!in.ok) { g_createError = "mi_world_restore: truncated snapshot"; delete world; return nullptr; }
+	w.topologyDirty = true; w.jointsDirty = true;
+	return world;
+}
 const char* mi_last_error(mi_world* world) { return world ? world->w.lastErrorText.c_str() : g_createError.c_str(); }
 
 uint32_t mi_add_body(mi_world* world, int kinematic, float gravityFactor, float linearDamping, float angularDamping, const float pos[3], const float rot[4])

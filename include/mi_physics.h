@@ -70,6 +70,12 @@ typedef struct mi_stats
 /* ---- lifetime ------------------------------------------------------------------------------------------------ */
 mi_world* mi_world_create(const mi_world_desc* desc);                 /* replaces game_scene + memory_arena ownership (physics.cpp:1205,1361) */
 void mi_world_destroy(mi_world* w);
+/* Checkpoint / resume (the engine's scene files — serialization_yaml.cpp:72-230, serialization_binary.cpp:225-260 —
+ * are asset formats and out of scope): a self-contained binary image of the world (bodies with current state and mass properties,
+ * colliders, hull geometries, joints).  A world restored from it continues bit-identically. */
+uint64_t mi_snapshot_size(mi_world* w);
+int mi_snapshot_save(mi_world* w, void* buffer, uint64_t capacity);
+mi_world* mi_world_restore(const mi_world_desc* desc, const void* buffer, uint64_t size); /* NULL on error: mi_last_error(NULL) */
 const char* mi_last_error(mi_world* w);                               /* w may be NULL for create-time errors */
 
 /* ---- add API --------------------------------------------------------------------------------------------------- */
