@@ -24,7 +24,48 @@ MI_DEV u64 claimKey(u32 round, u32 slot) { return ((u64)(0xFFFFu - round) << 48)
 // Active list: manifolds with at least one contact, appended with one wave-aggregated atomic per wave.  The list order is
 // arbitrary; nothing downstream depends on it (claims are keyed by slot, a colour's members are mutually independent).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_active_list(u32* __restrict__ counters, const ManifoldRec* __restrict__ manifolds, uint4* __restrict__ actIds, u32* __restrict__ mColor)
+// ---------------------------------------------------------------------------------------------------------------
+// Warm start of the colouring.  Most manifolds persist from step to step; a persisting manifold keeps last step's colour (two
+// persisting manifolds on one body had different colours then, so they still have), and only the new ones go through the claim
+// rounds — 3-6 rounds instead of ~24.  Last step's colours live in a hash table keyed by the collider pair (open addressing,
+// 64-bit entries {valid:1, colliderLo:28, colliderHi:28, colour:6}, two tables used alternately so that one can be cleared while the other is
+// read).  Kept colours are never lowered, so the palette slowly spreads: every 16th step (and whenever the colour count nears the
+// 64-colour limit, after a snapshot, or on request) the world is coloured from scratch.
+// ---------------------------------------------------------------------------------------------------------------
+#define COLOR_HASH_EMPTY 0ull
+MI_DEV u64 colorHashKey(u32 ia, u32 ib) { u32 lo = min(ia, ib), hi = max(ia, ib); return ((u64)(lo & 0x0FFFFFFFu) << 34) | ((u64)(hi & 0x0FFFFFFFu) << 6); } // colour goes into the low 6 bits
+MI_DEV u32 colorHashSlot(u64 key, u32 mask) { u64 k = key >> 6; k ^= k >> 29; k *= 0xbf58476d1ce4e5b9ull; k ^= k >> 32; return (u32)k & mask; }
+// entry = key | colour, with bit 63 set so that a valid entry is never COLOR_HASH_EMPTY (colliders < 2^28)
+MI_DEV u32 colorHashLookup(const u64* __restrict__ table, u32 mask, u64 key)
+{
+	u32 h = colorHashSlot(key, mask);
+	for (u32 probe = 0; probe < 64; ++probe)
+	{
+		u64 e = table[(h + probe) & mask];
+		if (e == COLOR_HASH_EMPTY) return UNCOLORED;
+		if ((e & ~0x3Full) == (key | (1ull << 63))) return (u32)(e & 0x3Full);
+	}
+	return UNCOLORED;
+}
+__global__ void __launch_bounds__(256) k_color_store(const u32* __restrict__ counters, const uint4* __restrict__ actIds, const u32* __restrict__ mColor,
+	const u64* __restrict__ pairSorted, u64* __restrict__ table, u32 mask)
+{
+	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= counters[CTR_NUM_ACTIVE]) return;
+	u32 c = mColor[j];
+	if (c >= MI_MAX_COLORS) return;
+	u64 packed = pairSorted[actIds[j].w];
+	u64 key = colorHashKey((u32)packed, (u32)(packed >> 32)) | (1ull << 63);
+	u32 h = colorHashSlot(key & ~(1ull << 63), mask);
+	for (u32 probe = 0; probe < 64; ++probe) // a table four times the manifold count: 64 probes practically always suffice; a miss only costs a recolouring
+	{
+		unsigned long long old = atomicCAS((unsigned long long*)&table[(h + probe) & mask], COLOR_HASH_EMPTY, key | c);
+		if (old == COLOR_HASH_EMPTY) return;
+	}
+}
+
+__global__ void __launch_bounds__(1024) k_active_list(u32* __restrict__ counters, const ManifoldRec* __restrict__ manifolds, uint4* __restrict__ actIds, u32* __restrict__ mColor,
+	const u64* __restrict__ pairSorted, const u64* __restrict__ warmTable, u32 warmMask, u32 nb, u64* __restrict__ bodyMask)
 {
 	// ONE pair of global atomics per 1024-lane workgroup: same-address atomics from all over the chip serialise (two per wave cost
 	// 100 us at 500k candidate pairs).  Waves reserve their ranges in an LDS counter, lane 0 of the workgroup reserves the global range.
@@ -53,7 +94,18 @@ __global__ void __launch_bounds__(1024) k_active_list(u32* __restrict__ counters
 	if (!active) return;
 	u32 j = sBase + waveBase + (u32)__popcll(mask & ((1ull << lane) - 1ull));
 	actIds[j] = make_uint4(ids.x, ids.y, ids.z, m);
-	mColor[j] = UNCOLORED;
+	u32 c = UNCOLORED;
+	if (warmTable) // this manifold existed last step: keep its colour
+	{
+		u64 packed = pairSorted[m];
+		c = colorHashLookup(warmTable, warmMask, colorHashKey((u32)packed, (u32)(packed >> 32)));
+		if (c != UNCOLORED)
+		{
+			if (ids.x < nb) atomicOr((unsigned long long*)&bodyMask[ids.x], 1ull << c);
+			if (ids.y < nb) atomicOr((unsigned long long*)&bodyMask[ids.y], 1ull << c);
+		}
+	}
+	mColor[j] = c;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -350,7 +402,18 @@ void launch_coloring(World& w, u32 numPairs)
 		MI_CHECK(hipMemsetAsync(w.bodyMask.p, 0, sizeof(u64) * (nb + 1), w.stream));
 		MI_CHECK(hipMemsetAsync(w.claim.p, 0xFF, sizeof(u64) * 2 * (nb + 1), w.stream));
 	}
-	hipLaunchKernelGGL(k_active_list, dim3((numPairs + 1023) / 1024), dim3(1024), 0, w.stream, w.dCounters.p, w.manifolds.p, w.actIds.p, w.mColor.p);
+	// warm start: last step's colours by collider pair, unless it is time for a colouring from scratch
+	u32 tableSize = 1024; while (tableSize < 4u * std::max<u32>(numPairs, w.lastNumManifolds)) tableSize <<= 1;
+	bool sizeChanged = w.colorHash[0].cap < tableSize;
+	for (int t = 0; t < 2; ++t) if (w.colorHash[t].cap < tableSize) w.colorHash[t].ensure(tableSize, w.stream);
+	if (sizeChanged) w.colorHashSize = 0;
+	bool warm = w.useWarmColoring && w.colorHashSize == tableSize && !w.forceFullColoring && w.stepsSinceFullColoring < w.fullColoringInterval && w.nc < (1u << 28)
+		&& w.hCounters[CTR_NUM_COLORS] < 48 && flow_num_regions(w) == 1;
+	w.stepsSinceFullColoring = warm ? w.stepsSinceFullColoring + 1 : 0;
+	w.forceFullColoring = false;
+	const u64* readTable = warm ? w.colorHash[w.colorHashCur].p : nullptr;
+	hipLaunchKernelGGL(k_active_list, dim3((numPairs + 1023) / 1024), dim3(1024), 0, w.stream, w.dCounters.p, w.manifolds.p, w.actIds.p, w.mColor.p,
+		(const u64*)w.pairsSorted.p, readTable, tableSize - 1, nb, w.bodyMask.p);
 	// the active count is not known on the host yet: size the round launches by last step's count (+25 %), never above numPairs
 	u32 est = w.lastNumManifolds ? std::min<u32>(numPairs, w.lastNumManifolds + w.lastNumManifolds / 4 + 1024) : numPairs;
 	dim3 rgrid((est + 255) / 256);
@@ -373,6 +436,13 @@ void launch_coloring(World& w, u32 numPairs)
 		u32 rounds = w.coloringRounds;
 		for (u32 r = 0; r <= rounds; ++r)
 			hipLaunchKernelGGL(k_color_round, (r == rounds) ? grid : rgrid, block, 0, w.stream, w.dCounters.p, nb, r, rounds, w.actIds.p, w.mColor.p, w.bodyMask.p, w.claim.p);
+	}
+	if (w.useWarmColoring) // remember this step's colours for the next one (in the other table)
+	{
+		u32 other = w.colorHashCur ^ 1u;
+		MI_CHECK(hipMemsetAsync(w.colorHash[other].p, 0, sizeof(u64) * tableSize, w.stream));
+		hipLaunchKernelGGL(k_color_store, rgrid.x >= grid.x ? grid : grid, block, 0, w.stream, w.dCounters.p, w.actIds.p, w.mColor.p, (const u64*)w.pairsSorted.p, w.colorHash[other].p, tableSize - 1);
+		w.colorHashCur = other; w.colorHashSize = tableSize;
 	}
 	hipLaunchKernelGGL(k_color_keys, grid, block, 0, w.stream, w.dCounters.p, numPairs, w.actIds.p, w.mColor.p, w.mKey.p, w.mIdx.p);
 	csort_pairs_u32(w, w.mKey.p, w.mKeySorted.p, w.mIdx.p, w.mOrder.p, numPairs, KEY_INACTIVE + 1);

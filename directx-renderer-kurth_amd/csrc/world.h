@@ -147,6 +147,8 @@ struct World
 	// settings snapshot for the running step
 	u32 iterations = 30;
 	u32 coloringRounds = 24;     // adaptive: last useful round of the previous step + margin (launch-per-round colouring only)
+	DevBuf<u64> colorHash[2]; u32 colorHashCur = 0, colorHashSize = 0, stepsSinceFullColoring = 0, fullColoringInterval = 16; // warm-started colouring (MI_PHYSICS_NO_WARM_COLORING=1: from scratch every step)
+	bool useWarmColoring = true, forceFullColoring = true;
 	bool useFusedColoring = true; u32 colorMaxBlocks = 0; // all colouring rounds in one launch with a grid barrier (MI_PHYSICS_NO_FUSED_COLORING=1: one launch per round)
 	u32 lastNumManifolds = 0;    // sizes the colouring-round launches of the next step
 	mi_stats stats = {};

@@ -50,6 +50,8 @@ World::World(int dev) : device(dev)
 	useFlow = getenv("MI_PHYSICS_NO_FLOW") == nullptr;   // dataflow contact sweep (one launch) vs one launch per colour
 	useFlowRegions = getenv("MI_FLOW_REGIONS") != nullptr;
 	useFusedColoring = getenv("MI_PHYSICS_NO_FUSED_COLORING") == nullptr;
+	useWarmColoring = getenv("MI_PHYSICS_NO_WARM_COLORING") == nullptr;
+	if (const char* e = getenv("MI_COLOR_FULL_INTERVAL")) fullColoringInterval = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_MAX")) flowMaxManifolds = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_EAGER")) flowEagerMax = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_TEST_ABORT")) flowTestAbortStep = (u32)atoi(e); // tests: make the dataflow sweep of that internal step give up
@@ -699,6 +701,7 @@ namespace
 	struct BodyPod { float pos[3], rot[4], localCOG[3], invMass, invInertia[9], gravityFactor, linDamp, angDamp, v[3], w[3], force[3], torque[3]; uint32_t removed; };
 	void serialize(World& w, BlobWriter& out)
 	{
+		w.forceFullColoring = true; // the image has no colour history: this world and the restored one both colour from scratch next step
 		w.upload();
 		if (w.stateOnDevice) w.downloadState();
 		out.pod(SNAPSHOT_MAGIC); out.pod(SNAPSHOT_VERSION);
