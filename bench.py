@@ -111,18 +111,20 @@ def main():
         stepper.step_internal(scene.dt)
     for _ in range(args.warmup):
         stepper.step_internal(scene.dt)
-    stepper.enable_stage_timing(True)  # HIP events on the world's stream, inside the timed region
-    acc = {}
+    stepper.stats()                    # clears the running means
+    stepper.enable_stage_timing(True)  # HIP events on the world's stream around every stage of every timed step (read back in batches, no per-step stall)
     barrier(); sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stepper.step_internal(scene.dt)
-        st = stepper.stats()
-        for k, v in st.items():
-            acc[k] = acc.get(k, 0.0) + v
     barrier(); sync()
     elapsed = time.perf_counter() - t0
+    st = stepper.stats()               # stage times and counts: means over exactly the timed steps
     stepper.enable_stage_timing(False)
+    assert st["avgSteps"] == args.steps, st["avgSteps"]
+    acc = {k: v * args.steps for k, v in st.items()}
+    for k, a in (("numContacts", "avgContacts"), ("numCollisions", "avgCollisions"), ("numColors", "avgColors"), ("numBroadphaseOverlaps", "avgBroadphaseOverlaps"), ("flowProbes", "avgFlowProbes")):
+        acc[k] = st[a] * args.steps
 
     if world_size > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")

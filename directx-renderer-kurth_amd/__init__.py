@@ -50,7 +50,9 @@ class Stats(C.Structure):
                 ("numContacts", C.c_uint32), ("numColors", C.c_uint32), ("numJoints", C.c_uint32), ("numInternalSteps", C.c_uint32),
                 ("numGraphBuilds", C.c_uint32), ("coloringRounds", C.c_uint32), ("flowProbes", C.c_uint32), ("numFlowRecoveries", C.c_uint32),
                 ("msCollidersBroad", C.c_float), ("msNarrow", C.c_float), ("msSolverSetup", C.c_float), ("msSolve", C.c_float),
-                ("msIntegrate", C.c_float), ("msTotal", C.c_float)]
+                ("msIntegrate", C.c_float), ("msTotal", C.c_float),
+                ("avgContacts", C.c_float), ("avgCollisions", C.c_float), ("avgColors", C.c_float), ("avgBroadphaseOverlaps", C.c_float), ("avgFlowProbes", C.c_float),
+                ("avgSteps", C.c_uint32)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

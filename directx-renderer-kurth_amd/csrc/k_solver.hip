@@ -886,6 +886,9 @@ __global__ void __launch_bounds__(256, BLOCKS_PER_CU) k_solve_flow(u32* counters
 	}
 	const bool single = (end - begin) <= stride;
 	u32 probes = 0;
+	// The host may have launched without looking at the schedule: manifolds in the serial bucket (more than 64 colours) have no rank
+	// in their bodies' colour masks, so this kernel cannot run them — give up at once, the host redoes the step with launches.
+	if (counters[CTR_KEY_START + 4 * MI_SERIAL_COLOR + 4] != counters[CTR_KEY_START + 4 * MI_SERIAL_COLOR]) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(status, 32u); return; }
 	bool aborted = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 	if (!aborted)
 	{

@@ -152,8 +152,16 @@ struct World
 	bool useFusedColoring = true; u32 colorMaxBlocks = 0; // all colouring rounds in one launch with a grid barrier (MI_PHYSICS_NO_FUSED_COLORING=1: one launch per round)
 	u32 lastNumManifolds = 0;    // sizes the colouring-round launches of the next step
 	mi_stats stats = {};
-	std::vector<hipEvent_t> stageEvents;
+	// Stage timing: HIP events of the last STAGE_RING timed steps, read back without stalling every step (mi_get_stats harvests them)
+	static const u32 STAGE_RING = 32;
+	std::vector<hipEvent_t> stageEvents;  // STAGE_RING x 6
+	u32 ringHead = 0, ringPending = 0, accTimed = 0; double accMs[5] = { 0, 0, 0, 0, 0 };
 	bool timeStages = false;
+	void harvestTiming();
+	// Counts of the steps since the last mi_get_stats (the host learns a step's counts at its next synchronisation)
+	double sumContacts = 0, sumManifolds = 0, sumColors = 0, sumPairs = 0, sumProbes = 0; u32 sumSteps = 0, countedStep = 0, prevNumPairs = 0;
+	bool useSync2 = false;                // MI_PHYSICS_SYNC2=1: read the colour table back every step even when the dataflow sweep does not need it
+	void countPreviousStep(); void refreshCounters();
 
 	// The N-iteration solver sweep (joint colours + contact colours per iteration) replayed as one hipGraph.  Launch arguments are
 	// step-invariant (ranges live in dCounters), so a graph is rebuilt only when the colour count, a colour's size class, the joint

@@ -44,12 +44,13 @@ World::World(int dev) : device(dev)
 	if (hCounters) memset(hCounters, 0, CTR_WORDS * sizeof(u32));
 	dCounters.ensure(CTR_WORDS, stream);
 	if (dCounters.p) MI_CHECK(hipMemsetAsync(dCounters.p, 0, CTR_WORDS * sizeof(u32), stream));
-	stageEvents.resize(8);
+	stageEvents.resize(STAGE_RING * 6);
 	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
 	useGraph = getenv("MI_PHYSICS_NO_GRAPH") == nullptr; // rocprofv3's kernel trace needs plain launches
 	useFlow = getenv("MI_PHYSICS_NO_FLOW") == nullptr;   // dataflow contact sweep (one launch) vs one launch per colour
 	useFlowRegions = getenv("MI_FLOW_REGIONS") != nullptr;
 	useFusedColoring = getenv("MI_PHYSICS_NO_FUSED_COLORING") == nullptr;
+	useSync2 = getenv("MI_PHYSICS_SYNC2") != nullptr;
 	useWarmColoring = getenv("MI_PHYSICS_NO_WARM_COLORING") == nullptr;
 	if (const char* e = getenv("MI_COLOR_FULL_INTERVAL")) fullColoringInterval = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_MAX")) flowMaxManifolds = (u32)atoi(e);
@@ -529,7 +530,7 @@ void World::recoverFlow()
 	if (rowCap) MI_CHECK(hipMemsetAsync(rowLambda.p, 0, sizeof(float2) * (size_t)MI_MAX_CONTACTS_PER_MANIFOLD * rowCap, stream));
 	launch_joint_init(*this, pendingDt);
 	bool flow = useFlow; useFlow = false;
-	runSolverSweep(*this, pendingIters, hCounters[CTR_NUM_PAIRS] ? hCounters[CTR_NUM_COLORS] : 0);
+	runSolverSweep(*this, pendingIters, prevNumPairs ? hCounters[CTR_NUM_COLORS] : 0);
 	useFlow = flow;
 	launch_integrate_velocities(*this, pendingDt);
 }
@@ -551,6 +552,45 @@ int World::resolvePendingFlow()
 	return lastError;
 }
 
+void World::harvestTiming()
+{
+	if (!ringPending) return;
+	MI_CHECK(hipStreamSynchronize(stream));
+	for (u32 k = 0; k < ringPending; ++k)
+	{
+		u32 slot = (ringHead + STAGE_RING - ringPending + k) % STAGE_RING;
+		for (int i = 0; i < 5; ++i) { float ms = 0.f; (void)hipEventElapsedTime(&ms, stageEvents[slot * 6 + i], stageEvents[slot * 6 + i + 1]); accMs[i] += ms; }
+		accTimed++;
+	}
+	ringPending = 0;
+}
+
+// hCounters holds the colour / manifold / contact counts of the step before the current one whenever the host has just read the
+// counters at a step's first synchronisation: add them to the running sums once.
+void World::countPreviousStep()
+{
+	if (countedStep >= stats.numInternalSteps) return;
+	countedStep = stats.numInternalSteps;
+	bool had = prevNumPairs != 0;
+	stats.numCollisions = had ? hCounters[CTR_NUM_MANIFOLDS] : 0; stats.numContacts = had ? hCounters[CTR_NUM_CONTACTS] : 0;
+	stats.numColors = had ? hCounters[CTR_NUM_COLORS] : 0; stats.flowProbes = hCounters[CTR_FLOW_PROBES];
+	stats.numBroadphaseOverlaps = prevNumPairs;
+	lastNumManifolds = stats.numCollisions;
+	sumContacts += stats.numContacts; sumManifolds += stats.numCollisions; sumColors += stats.numColors; sumPairs += prevNumPairs; sumProbes += stats.flowProbes; sumSteps++;
+}
+
+// Bring hCounters (and the statistics) up to date with the device: needed by whoever looks at the last step's schedule or counts
+// when the step did not read the colour table back itself.
+void World::refreshCounters()
+{
+	if (countedStep >= stats.numInternalSteps) return;
+	resolvePendingFlow();
+	readCounters(*this);
+	if (!prevNumPairs) { memset(hCounters + CTR_KEY_START, 0, sizeof(u32) * (MI_NUM_SCHEDULE_KEYS + 1)); hCounters[CTR_NUM_MANIFOLDS] = 0; hCounters[CTR_NUM_VALID] = 0; hCounters[CTR_NUM_COLORS] = 0; }
+	hCounters[CTR_NUM_PAIRS] = prevNumPairs; // (the pair count of the finished step; the device word is the same until the next broadphase)
+	countPreviousStep();
+}
+
 int World::stepInternal(float dt, u32 iters)
 {
 	g_currentWorld = this;
@@ -560,7 +600,14 @@ int World::stepInternal(float dt, u32 iters)
 	if (!nb) return MI_OK;
 	iterations = iters;
 	bool T = timeStages;
-	if (T) MI_CHECK(hipEventRecord(stageEvents[0], stream));
+	hipEvent_t* ev = nullptr;
+	if (T)
+	{
+		if (ringPending == STAGE_RING) harvestTiming();
+		ev = &stageEvents[ringHead * 6];
+		ringHead = (ringHead + 1) % STAGE_RING; ringPending++;
+		MI_CHECK(hipEventRecord(ev[0], stream));
+	}
 
 	launch_build_colliders(*this);
 	launch_broadphase_count(*this);
@@ -580,14 +627,15 @@ int World::stepInternal(float dt, u32 iters)
 		readCounters(*this);
 	}
 	flowPending = false;
-	stats.flowProbes = hCounters[CTR_FLOW_PROBES];
+	countPreviousStep();                                   // the counters just read hold the previous step's colour / contact counts
+	u32 prevColors = stats.numInternalSteps ? stats.numColors : 0xFFFFu;
 	u32 numPairs = hCounters[CTR_NUM_PAIRS];
 	ensurePairBuffers(*this, numPairs);
 	launch_broadphase_write(*this, numPairs);
-	if (T) MI_CHECK(hipEventRecord(stageEvents[1], stream));
+	if (T) MI_CHECK(hipEventRecord(ev[1], stream));
 
 	launch_narrowphase(*this, numPairs);
-	if (T) MI_CHECK(hipEventRecord(stageEvents[2], stream));
+	if (T) MI_CHECK(hipEventRecord(ev[2], stream));
 
 	flow_choose_regions(*this);
 	launch_integrate_forces(*this, dt);
@@ -595,7 +643,28 @@ int World::stepInternal(float dt, u32 iters)
 	launch_contact_init(*this, numPairs, dt);
 	launch_joint_init(*this, dt);
 	u32 numColors = 0;
-	if (numPairs)
+	if (flowCooldown) --flowCooldown;
+	// The dataflow sweep sizes itself on the device: the host only needs an estimate of the manifold count (last step's + 3 %; it
+	// decides between the one-manifold-per-lane build and the strided one, so it must not be generous; fewer lanes than manifolds is
+	// still correct, lanes then take several).  So the second synchronisation of the step is skipped
+	// while the colour count is comfortably below the 64-colour limit (the kernel checks the limit itself and gives up if it is hit:
+	// World::recoverFlow).  The launch sweep needs the colour table on the host and keeps the synchronisation.
+	bool noSync2 = useFlow && !flowCooldown && !useSync2 && numPairs && useFusedColoring && flow_num_regions(*this) == 1
+		&& prevColors + 8u < MI_MAX_COLORS && lastNumManifolds > 0;
+	if (noSync2)
+	{
+		u32 est = std::min<u32>(numPairs, lastNumManifolds + lastNumManifolds / 32 + 512);
+		if (T) MI_CHECK(hipEventRecord(ev[3], stream));
+		velBackup.ensure(2 * ((size_t)nb + 1), stream);
+		MI_CHECK(hipMemcpyAsync(velBackup.p, vel.p, sizeof(float4) * 2 * ((size_t)nb + 1), hipMemcpyDeviceToDevice, stream));
+		pendingDt = dt; pendingIters = iters; flowPending = true;
+		u32 numJointKernels = 0;
+		for (auto& js : joints) numJointKernels += js.colorStart.empty() ? 0 : (u32)js.colorStart.size() - 1;
+		hCounters[CTR_KEY_START] = 0; // launch_solve_flow subtracts the first slot of its first colour: colour 0 starts at slot 0
+		if (!numJointKernels) launch_solve_flow(*this, est, 0, iters, 0);
+		else for (u32 it = 0; it < iters; ++it) { launch_joint_solve_iteration(*this); launch_solve_flow(*this, est, it, it + 1, 0); }
+	}
+	else if (numPairs)
 	{
 		readCounters(*this);                               // sync #2: colour boundaries of the contact schedule
 		numColors = hCounters[CTR_NUM_COLORS];
@@ -605,38 +674,32 @@ int World::stepInternal(float dt, u32 iters)
 		coloringRounds = hCounters[CTR_OVERFLOW] ? std::min(1024u, coloringRounds * 2) : std::max(12u, lastUseful + 6);
 	}
 	else { memset(hCounters + CTR_KEY_START, 0, sizeof(u32) * (MI_NUM_SCHEDULE_KEYS + 1)); hCounters[CTR_NUM_MANIFOLDS] = 0; hCounters[CTR_NUM_VALID] = 0; lastNumManifolds = 0; }
-	if (T) MI_CHECK(hipEventRecord(stageEvents[3], stream));
+	if (T && !noSync2) MI_CHECK(hipEventRecord(ev[3], stream));
 
-	if (flowCooldown) --flowCooldown;
-	bool flowStep = useFlow && !flowCooldown && numPairs && numColors;
+	bool flowStep = !noSync2 && useFlow && !flowCooldown && numPairs && numColors;
 	if (flowStep) // pre-solve velocities, in case the dataflow sweep has to be redone (World::recoverFlow)
 	{
 		velBackup.ensure(2 * ((size_t)nb + 1), stream);
 		MI_CHECK(hipMemcpyAsync(velBackup.p, vel.p, sizeof(float4) * 2 * ((size_t)nb + 1), hipMemcpyDeviceToDevice, stream));
 		pendingDt = dt; pendingIters = iters; flowPending = true;
 	}
+	if (!noSync2)
 	{
 		bool flow = useFlow; useFlow = flowStep;
 		runSolverSweep(*this, iters, numPairs ? numColors : 0);
 		useFlow = flow;
 	}
-	if (T) MI_CHECK(hipEventRecord(stageEvents[4], stream));
+	if (T) MI_CHECK(hipEventRecord(ev[4], stream));
 
 	launch_integrate_velocities(*this, dt);
-	if (T) MI_CHECK(hipEventRecord(stageEvents[5], stream));
+	if (T) MI_CHECK(hipEventRecord(ev[5], stream));
 
-	stats.numRigidBodies = nb; stats.numColliders = nc; stats.numBroadphaseOverlaps = numPairs;
-	stats.numCollisions = hCounters[CTR_NUM_MANIFOLDS]; stats.numContacts = numPairs ? hCounters[CTR_NUM_CONTACTS] : 0; stats.numColors = numColors; stats.numInternalSteps++;
+	stats.numRigidBodies = nb; stats.numColliders = nc;
+	prevNumPairs = numPairs;
+	stats.numInternalSteps++;
+	if (!noSync2) countPreviousStep(); // this step's counts are on the host already (hCounters comes from its own second read)
 	u32 nj = 0; for (auto& js : joints) nj += (u32)js.order.size();
 	stats.numJoints = nj; stats.coloringRounds = coloringRounds;
-	if (T)
-	{
-		MI_CHECK(hipStreamSynchronize(stream));
-		float ms[5] = { 0, 0, 0, 0, 0 };
-		for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms[i], stageEvents[i], stageEvents[i + 1]);
-		stats.msCollidersBroad = ms[0]; stats.msNarrow = ms[1]; stats.msSolverSetup = ms[2]; stats.msSolve = ms[3]; stats.msIntegrate = ms[4];
-		stats.msTotal = ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
-	}
 	return lastError;
 }
 
@@ -1313,8 +1376,28 @@ int mi_read_mass_properties(mi_world* world, float* out13, uint32_t n)
 	}
 	return MI_OK;
 }
-int mi_get_stats(mi_world* world, mi_stats* out) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); *out = W->stats; return MI_OK; }
-int mi_enable_stage_timing(mi_world* world, int enable) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); W->timeStages = enable != 0; return MI_OK; }
+int mi_get_stats(mi_world* world, mi_stats* out)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->refreshCounters();     // counts of the last step (one small read-back if the step did not do it itself)
+	W->harvestTiming();
+	mi_stats& st = W->stats;
+	if (W->accTimed)
+	{
+		double n = W->accTimed;
+		st.msCollidersBroad = (float)(W->accMs[0] / n); st.msNarrow = (float)(W->accMs[1] / n); st.msSolverSetup = (float)(W->accMs[2] / n); st.msSolve = (float)(W->accMs[3] / n); st.msIntegrate = (float)(W->accMs[4] / n);
+		st.msTotal = st.msCollidersBroad + st.msNarrow + st.msSolverSetup + st.msSolve + st.msIntegrate;
+		for (double& a : W->accMs) a = 0; W->accTimed = 0;
+	}
+	st.avgSteps = W->sumSteps;
+	double n = W->sumSteps ? W->sumSteps : 1;
+	st.avgContacts = (float)(W->sumContacts / n); st.avgCollisions = (float)(W->sumManifolds / n); st.avgColors = (float)(W->sumColors / n);
+	st.avgBroadphaseOverlaps = (float)(W->sumPairs / n); st.avgFlowProbes = (float)(W->sumProbes / n);
+	W->sumContacts = W->sumManifolds = W->sumColors = W->sumPairs = W->sumProbes = 0; W->sumSteps = 0;
+	*out = st;
+	return W->lastError;
+}
+int mi_enable_stage_timing(mi_world* world, int enable) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); if (!enable) W->harvestTiming(); W->timeStages = enable != 0; return MI_OK; }
 uint32_t mi_num_bodies(mi_world* world) { CHECK_WORLD(0); return (u32)W->bodies.size(); }
 uint32_t mi_num_colliders(mi_world* world) { CHECK_WORLD(0); return (u32)W->colliders.size(); }
 
@@ -1359,11 +1442,12 @@ int mi_state_from_device_buffers(mi_world* world, const void* dPose, const void*
 static void d2h(World* w, void* dst, const void* src, size_t bytes)
 {
 	w->resolvePendingFlow();
+	w->refreshCounters();
 	if (!bytes) return;
 	MI_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, w->stream)); MI_CHECK(hipStreamSynchronize(w->stream));
 }
-uint32_t mi_debug_num_pairs(mi_world* world) { CHECK_WORLD(0); return W->hCounters[CTR_NUM_PAIRS]; }
-int mi_debug_read_pairs(mi_world* world, uint32_t* out) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); d2h(W, out, W->pairs.p, sizeof(uint2) * W->hCounters[CTR_NUM_PAIRS]); return W->lastError; }
+uint32_t mi_debug_num_pairs(mi_world* world) { CHECK_WORLD(0); W->refreshCounters(); return W->hCounters[CTR_NUM_PAIRS]; }
+int mi_debug_read_pairs(mi_world* world, uint32_t* out) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); W->refreshCounters(); d2h(W, out, W->pairs.p, sizeof(uint2) * W->hCounters[CTR_NUM_PAIRS]); return W->lastError; }
 int mi_debug_read_world_colliders(mi_world* world, void* outColliders64, float* outAabbs6)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
@@ -1382,7 +1466,7 @@ int mi_debug_read_world_colliders(mi_world* world, void* outColliders64, float* 
 	}
 	return W->lastError;
 }
-uint32_t mi_debug_num_manifold_slots(mi_world* world) { CHECK_WORLD(0); return W->hCounters[CTR_NUM_PAIRS] ? W->hCounters[CTR_NUM_VALID] : 0; }
+uint32_t mi_debug_num_manifold_slots(mi_world* world) { CHECK_WORLD(0); W->refreshCounters(); return W->hCounters[CTR_NUM_PAIRS] ? W->hCounters[CTR_NUM_VALID] : 0; }
 int mi_debug_read_manifolds(mi_world* world, uint32_t* outPairs2, uint32_t* outCounts, void* outContacts4x32, uint32_t* outBodyPairs2)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
@@ -1409,6 +1493,7 @@ uint32_t mi_debug_num_colors(mi_world* world) { CHECK_WORLD(0); return MI_MAX_CO
 int mi_debug_read_schedule(mi_world* world, uint32_t* outManifoldSlots, uint32_t* outColorStart)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->refreshCounters();
 	u32 n = W->hCounters[CTR_NUM_PAIRS] ? W->hCounters[CTR_NUM_MANIFOLDS] : 0;
 	std::vector<uint4> ids(n);
 	d2h(W, ids.data(), W->rowIds.p, sizeof(uint4) * n); // rowIds[s].w = manifold slot executed at schedule position s

@@ -171,7 +171,7 @@ class SlabWorld:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         for i, k in enumerate(keys):
-            acc[k] = float(tmax[i]) if (k.startswith("ms") or k in ("numColors", "numRigidBodies", "numColliders", "numInternalSteps", "numGraphBuilds", "coloringRounds")) else float(t[i])
+            acc[k] = float(tmax[i]) if (k.startswith("ms") or k in ("numColors", "avgColors", "avgSteps", "numRigidBodies", "numColliders", "numInternalSteps", "numGraphBuilds", "coloringRounds")) else float(t[i])
 
     def owned_mask(self):
         return (self.code == OWNED).cpu().numpy()

@@ -64,7 +64,9 @@ typedef struct mi_stats
 	uint32_t numGraphBuilds, coloringRounds; /* solver-sweep hipGraph (re)builds so far; colouring round budget of the last step */
 	uint32_t flowProbes;                     /* dataflow contact sweep: body-record polls of the step before the last one (0 = launch sweep) */
 	uint32_t numFlowRecoveries;              /* steps whose dataflow sweep gave up and was redone with the launch sweep (should stay 0) */
-	float msCollidersBroad, msNarrow, msSolverSetup, msSolve, msIntegrate, msTotal; /* HIP-event times, only when timing is enabled */
+	float msCollidersBroad, msNarrow, msSolverSetup, msSolve, msIntegrate, msTotal; /* HIP-event times, mean over the timed steps since the previous mi_get_stats (timing enabled only) */
+	float avgContacts, avgCollisions, avgColors, avgBroadphaseOverlaps, avgFlowProbes; /* means over the internal steps since the previous mi_get_stats */
+	uint32_t avgSteps;                                                                 /* ... and how many steps that was */
 } mi_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------ */
