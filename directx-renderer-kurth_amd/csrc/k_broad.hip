@@ -127,10 +127,17 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* 
 		}
 	}
 	u32 n = 0;
+	u32 hit0 = 0, hit1 = 0, hit2 = 0, hit3 = 0; // the first four partners of this lane stay in registers: the write pass then needs no second visit
 	for (u32 u = s; u < e; ++u)
 	{
 		if (checkKey && sCellKey[u] != nkey) continue;
-		if (aabbOverlap(amin, amax, sMin[u], sMax[u])) ++n;
+		float4 bmin = sMin[u];
+		if (aabbOverlap(amin, amax, bmin, sMax[u]))
+		{
+			u32 partner = __float_as_uint(bmin.w);
+			if (n == 0) hit0 = partner; else if (n == 1) hit1 = partner; else if (n == 2) hit2 = partner; else if (n == 3) hit3 = partner;
+			++n;
+		}
 	}
 	// exclusive prefix over the 16 lanes of the group (the groups of a wave are aligned to 16 lanes)
 	u32 incl = n;
@@ -141,6 +148,15 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* 
 	if (!n) return;
 	size_t base = (MODE == MODE_WRITE) ? (size_t)pairOffset[t] : (size_t)t * PAIR_SLAB;
 	u32 room = (MODE == MODE_WRITE) ? 0xFFFFFFFFu : PAIR_SLAB;
+	if (n <= 4)
+	{
+		for (u32 k = 0; k < n; ++k)
+		{
+			u32 partner = k == 0 ? hit0 : (k == 1 ? hit1 : (k == 2 ? hit2 : hit3));
+			if (pos + k < room && (MODE == MODE_SLAB || base + pos + k < pairCap)) out[base + pos + k] = make_uint2(me, partner);
+		}
+		return;
+	}
 	for (u32 u = s; u < e; ++u)
 	{
 		if (checkKey && sCellKey[u] != nkey) continue;
