@@ -58,11 +58,18 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+# mi_event (include/mi_physics.h): trigger_event / collision_begin_event / collision_end_event as one record
+EVENT_DTYPE = np.dtype([("kind", "<u4"), ("step", "<u4"), ("a", "<u4"), ("b", "<u4"), ("bodyA", "<u4"), ("bodyB", "<u4"),
+                        ("position", "<f4", 3), ("normal", "<f4", 3), ("relativeVelocity", "<f4", 3)])
+TRIGGER_ENTER, TRIGGER_LEAVE, COLLISION_BEGIN, COLLISION_END = range(4)
+
 EXPORTED_SYMBOLS = [
     "mi_world_create", "mi_world_destroy", "mi_last_error", "mi_snapshot_size", "mi_snapshot_save", "mi_world_restore", "mi_add_body", "mi_add_hull_geometry", "mi_add_collider", "mi_add_static_collider",
     "mi_add_distance_constraint_local", "mi_add_distance_constraint_global", "mi_add_ball_constraint_local", "mi_add_ball_constraint_global",
     "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
-    "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_delete_all_constraints_from_body", "mi_delete_body", "mi_test_physics_interaction", "mi_apply_force_torque", "mi_set_velocity",
+    "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_delete_all_constraints_from_body", "mi_delete_body",
+    "mi_add_force_field", "mi_set_force_field", "mi_add_trigger", "mi_add_force_field_collider", "mi_add_trigger_collider", "mi_enable_collision_events", "mi_drain_events",
+    "mi_test_physics_interaction", "mi_apply_force_torque", "mi_set_velocity",
     "mi_set_transform", "mi_write_transforms", "mi_write_velocities", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
     "mi_get_stats", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_debug_num_pairs", "mi_debug_read_pairs",
     "mi_debug_read_world_colliders", "mi_debug_num_manifold_slots", "mi_debug_read_manifolds", "mi_debug_num_colors", "mi_debug_read_schedule",
@@ -109,7 +116,7 @@ def load_library():
         lib.mi_last_error.restype = C.c_char_p
         for name in EXPORTED_SYMBOLS:
             fn = getattr(lib, name)
-            if name.startswith("mi_add_") or name in ("mi_num_bodies", "mi_num_colliders", "mi_debug_num_pairs", "mi_debug_num_manifold_slots", "mi_debug_num_colors"):
+            if name.startswith("mi_add_") or name in ("mi_num_bodies", "mi_num_colliders", "mi_debug_num_pairs", "mi_debug_num_manifold_slots", "mi_debug_num_colors", "mi_drain_events"):
                 fn.restype = C.c_uint32
         _lib = lib
     return _lib
@@ -194,6 +201,41 @@ class World:
         s = np.zeros(10, np.float32); s[:len(shape)] = shape
         m = Material(*material)
         return self._id(self.lib.mi_add_static_collider(self.w, C.c_uint32(ctype), _f(s), C.byref(m), _f(pos), _f(rot)))
+
+    # ---- force fields, triggers, events (physics.h:182-203, 356-380; physics.cpp:759-787, 952-1178) ----
+    def add_force_field(self, force, pos=None, rot=None):
+        """force_field_component: without colliders it acts on every body, with colliders on the bodies overlapping them."""
+        return self._id(self.lib.mi_add_force_field(self.w, _f(force), _f(pos) if pos is not None else None, _f(rot) if rot is not None else None))
+
+    def set_force_field(self, field, force):
+        self._check(self.lib.mi_set_force_field(self.w, C.c_uint32(field), _f(force)))
+
+    def add_trigger(self, pos=None, rot=None):
+        """trigger_component: enter / leave events for rigid bodies overlapping its colliders come out of drain_events()."""
+        return self._id(self.lib.mi_add_trigger(self.w, _f(pos) if pos is not None else None, _f(rot) if rot is not None else None))
+
+    def add_force_field_collider(self, field, ctype, shape):
+        s = np.zeros(10, np.float32); s[:len(shape)] = shape
+        return self._id(self.lib.mi_add_force_field_collider(self.w, C.c_uint32(field), C.c_uint32(ctype), _f(s)))
+
+    def add_trigger_collider(self, trigger, ctype, shape):
+        s = np.zeros(10, np.float32); s[:len(shape)] = shape
+        return self._id(self.lib.mi_add_trigger_collider(self.w, C.c_uint32(trigger), C.c_uint32(ctype), _f(s)))
+
+    def enable_collision_events(self, begin=True, end=True):
+        """physics_settings::collisionBeginCallback / collisionEndCallback set; enable before the first step."""
+        self._check(self.lib.mi_enable_collision_events(self.w, int(begin), int(end)))
+
+    def drain_events(self, capacity=1 << 16):
+        """Pending trigger / collision events in the reference's callback order, as a structured array (EVENT_DTYPE)."""
+        chunks = []
+        while True:
+            out = np.zeros(capacity, EVENT_DTYPE)
+            n = self.lib.mi_drain_events(self.w, _p(out), C.c_uint32(capacity))
+            chunks.append(out[:n])
+            if n < capacity:
+                break
+        return np.concatenate(chunks) if len(chunks) > 1 else chunks[0]
 
     def add_distance_constraint_local(self, a, b, la, lb, distance):
         return self._id(self.lib.mi_add_distance_constraint_local(self.w, a, b, _f(la), _f(lb), C.c_float(distance)))

@@ -6,11 +6,13 @@
 // 1529-1584); the hull's support function walks its vertex list (collision_gjk.h:77-100).
 #include "world.h"
 #include <rocprim/rocprim.hpp>
+#include "events.h"
 #include <algorithm>
 
 void prim_sort_pairs_u32_u64(World& w, const u32* kin, u32* kout, const u64* vin, u64* vout, u32 n, u32 bits);
 
 #define KEY_INVALID 63u
+#define KEY_ZONE 62u   // rigid body vs force-field / trigger collider: boolean overlap check only (collision_narrow.cpp:2378-2395)
 
 struct Man { V3 n; float4 p[4]; u32 count; };
 
@@ -32,7 +34,8 @@ __global__ void __launch_bounds__(256) k_classify(const u32* __restrict__ counte
 	if ((rbA || rbB) && !(rbA && rbB && bA == bB) && typeSupported(tA) && typeSupported(tB)) // :2358-2369
 	{
 		if (!(tA < tB)) { u32 t = pr.x; pr.x = pr.y; pr.y = t; t = tA; tA = tB; tB = t; } // :2374 — swaps on equal types too
-		key = tA * 6 + tB;
+		u32 zone = (__float_as_uint(da.w) | __float_as_uint(db.w)) & 0xFFu; // a force-field / trigger collider is in the pair
+		key = zone ? KEY_ZONE : tA * 6 + tB;
 	}
 	pairKey[p] = key;
 	pairPacked[p] = ((u64)pr.y << 32) | pr.x;
@@ -44,8 +47,8 @@ __global__ void k_bucket_offsets(u32* __restrict__ counters, const u32* __restri
 	u32 n = counters[CTR_NUM_PAIRS];
 	u32 lo = 0, hi = n;
 	while (lo < hi) { u32 mid = (lo + hi) >> 1; if (keySorted[mid] < b) lo = mid + 1; else hi = mid; }
-	counters[CTR_BUCKET_START + b] = lo; // valid keys are <= 4*6+4 = 28; KEY_INVALID sorts last
-	if (b == KEY_INVALID) { counters[CTR_NUM_VALID] = lo; counters[CTR_EPA_COUNT] = 0; counters[CTR_EPA_COUNT_HULL] = 0; counters[CTR_NUM_ACTIVE] = 0; counters[CTR_NUM_CONTACTS] = 0; }
+	counters[CTR_BUCKET_START + b] = lo; // collision keys are <= 5*6+5 = 35; KEY_ZONE (overlap checks) and KEY_INVALID sort last: manifold slots end where KEY_ZONE starts
+	if (b == KEY_ZONE) { counters[CTR_NUM_VALID] = lo; counters[CTR_EPA_COUNT] = 0; counters[CTR_EPA_COUNT_HULL] = 0; counters[CTR_NUM_ACTIVE] = 0; counters[CTR_NUM_CONTACTS] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1080,6 +1083,107 @@ __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) k_epa(const u32* __r
 	}
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Non-collision interactions: rigid body vs force-field / trigger collider — overlapCheck, collision_narrow.cpp:1593-1689, over the
+// boolean tests of bounding_volumes.h:301-363 and bounding_volumes.cpp:704-835, 1079-1244.  One lane per pair of the KEY_ZONE bucket.
+// A hit sets the body's bit of the field (k_apply_fields adds the forces in ascending field id) or enters the
+// (trigger, body) pair into this step's overlap set (enter event if the previous step's set does not hold it).
+// ---------------------------------------------------------------------------------------------------------------
+MI_DEV bool ovSphereSphere(V3 ca, float ra, V3 cb, float rb) { V3 d = ca - cb; float dist2 = dot(d, d); float radiusSum = ra + rb; return dist2 <= radiusSum * radiusSum; }
+MI_DEV bool ovSphereCylinder(V3 sc, float sr, Capsule c) // bounding_volumes.cpp:704-724
+{
+	V3 ab = c.b - c.a;
+	float t = dot(sc - c.a, ab) / sqlen(ab);
+	if (t >= 0.f && t <= 1.f) return ovSphereSphere(sc, sr, lerp(c.a, c.b, t), c.r);
+	V3 p = (t <= 0.f) ? c.a : c.b;
+	V3 up = (t <= 0.f) ? -ab : ab;
+	V3 projectedDirToCenter = normalize(cross(cross(up, sc - p), up));
+	V3 endA = p + projectedDirToCenter * c.r;
+	V3 endB = p - projectedDirToCenter * c.r;
+	V3 closestToSphere = closestPointSegment(sc, endA, endB);
+	float sqDistance = sqlen(closestToSphere - sc);
+	return sqDistance <= sr; // sic (:723)
+}
+MI_DEV bool ovSphereBox(V3 sc, float sr, Box a) // bounding_volumes.h:320-326
+{
+	V3 p = v3(fminf(fmaxf(sc.x, a.lo.x), a.hi.x), fminf(fmaxf(sc.y, a.lo.y), a.hi.y), fminf(fmaxf(sc.z, a.lo.z), a.hi.z));
+	V3 n = p - sc;
+	return sqlen(n) <= sr * sr;
+}
+MI_DEV bool ovObbObb(const Obb& a, const Obb& b) // bounding_volumes.cpp:1079-1199
+{
+	V3 ax = a.q * v3(1.f, 0.f, 0.f), ay = a.q * v3(0.f, 1.f, 0.f), az = a.q * v3(0.f, 0.f, 1.f);
+	V3 bx = b.q * v3(1.f, 0.f, 0.f), by = b.q * v3(0.f, 1.f, 0.f), bz = b.q * v3(0.f, 0.f, 1.f);
+	M3 r;
+	r.m00 = dot(ax, bx); r.m10 = dot(ay, bx); r.m20 = dot(az, bx);
+	r.m01 = dot(ax, by); r.m11 = dot(ay, by); r.m21 = dot(az, by);
+	r.m02 = dot(ax, bz); r.m12 = dot(ay, bz); r.m22 = dot(az, bz);
+	V3 tw = b.c - a.c;
+	V3 t = conjugate(a.q) * tw;
+	M3 absR;
+	absR.m00 = fabsf(r.m00) + MI_EPSILON; absR.m10 = fabsf(r.m10) + MI_EPSILON; absR.m20 = fabsf(r.m20) + MI_EPSILON;
+	absR.m01 = fabsf(r.m01) + MI_EPSILON; absR.m11 = fabsf(r.m11) + MI_EPSILON; absR.m21 = fabsf(r.m21) + MI_EPSILON;
+	absR.m02 = fabsf(r.m02) + MI_EPSILON; absR.m12 = fabsf(r.m12) + MI_EPSILON; absR.m22 = fabsf(r.m22) + MI_EPSILON;
+	float ra, rb;
+	for (u32 i = 0; i < 3; ++i) { ra = vget(a.r, i); rb = dot(mrow(absR, i), b.r); if (ra + rb - fabsf(vget(t, i)) < 0.f) return false; }
+	for (u32 i = 0; i < 3; ++i) { ra = dot(mcol(absR, i), a.r); rb = vget(b.r, i); float d = dot(mcol(r, i), t); if (ra + rb - fabsf(d) < 0.f) return false; }
+#define MI_OV_EDGE(RA, RB, DIST) ra = RA; rb = RB; if (ra + rb - fabsf(DIST) < 0.f) return false;
+	MI_OV_EDGE(a.r.y * absR.m20 + a.r.z * absR.m10, b.r.y * absR.m02 + b.r.z * absR.m01, t.z * r.m10 - t.y * r.m20)
+	MI_OV_EDGE(a.r.y * absR.m21 + a.r.z * absR.m11, b.r.x * absR.m02 + b.r.z * absR.m00, t.z * r.m11 - t.y * r.m21)
+	MI_OV_EDGE(a.r.y * absR.m22 + a.r.z * absR.m12, b.r.x * absR.m01 + b.r.y * absR.m00, t.z * r.m12 - t.y * r.m22)
+	MI_OV_EDGE(a.r.x * absR.m20 + a.r.z * absR.m00, b.r.y * absR.m12 + b.r.z * absR.m11, t.x * r.m20 - t.z * r.m00)
+	MI_OV_EDGE(a.r.x * absR.m21 + a.r.z * absR.m01, b.r.x * absR.m12 + b.r.z * absR.m10, t.x * r.m21 - t.z * r.m01)
+	MI_OV_EDGE(a.r.x * absR.m22 + a.r.z * absR.m02, b.r.x * absR.m11 + b.r.y * absR.m10, t.x * r.m22 - t.z * r.m02)
+	MI_OV_EDGE(a.r.x * absR.m10 + a.r.y * absR.m00, b.r.y * absR.m22 + b.r.z * absR.m21, t.y * r.m00 - t.x * r.m10)
+	MI_OV_EDGE(a.r.x * absR.m11 + a.r.y * absR.m01, b.r.x * absR.m22 + b.r.z * absR.m20, t.y * r.m01 - t.x * r.m11)
+	MI_OV_EDGE(a.r.x * absR.m12 + a.r.y * absR.m02, b.r.x * absR.m21 + b.r.y * absR.m20, t.y * r.m02 - t.x * r.m12)
+#undef MI_OV_EDGE
+	return true;
+}
+MI_DEV bool overlapColliders(u32 key, const ColliderRec& A, const ColliderRec& B, const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts)
+{
+	switch (key)
+	{
+		case 0: { Sphere a = asSphere(A), b = asSphere(B); return ovSphereSphere(a.c, a.r, b.c, b.r); }
+		case 1: { Sphere s = asSphere(A); Capsule c = asCapsule(B); return ovSphereSphere(s.c, s.r, closestPointSegment(s.c, c.a, c.b), c.r); }
+		case 2: { Sphere s = asSphere(A); return ovSphereCylinder(s.c, s.r, asCapsule(B)); }
+		case 3: { Sphere s = asSphere(A); return ovSphereBox(s.c, s.r, asBox(B)); }
+		case 4: { Sphere s = asSphere(A); Obb o = asObb(B); Box b; b.lo = o.c - o.r; b.hi = o.c + o.r; return ovSphereBox(conjugate(o.q) * (s.c - o.c) + o.c, s.r, b); }
+		case 7: { Capsule a = asCapsule(A), b = asCapsule(B); V3 c1, c2; closestSegmentSegment(a.a, a.b, b.a, b.b, c1, c2); return ovSphereSphere(c1, a.r, c2, b.r); }
+		case 8: { Capsule a = asCapsule(A), b = asCapsule(B); V3 c1, c2; closestSegmentSegment(a.a, a.b, b.a, b.b, c1, c2); return ovSphereCylinder(c1, a.r, b); }
+		case 21: { Box a = asBox(A), b = asBox(B); return !(a.hi.x < b.lo.x || a.lo.x > b.hi.x || a.hi.y < b.lo.y || a.lo.y > b.hi.y || a.hi.z < b.lo.z || a.lo.z > b.hi.z); }
+		case 22: { Box b = asBox(A); Obb oa; oa.q = q4(0.f, 0.f, 0.f, 1.f); oa.c = boxCenter(b); oa.r = boxRadius(b); return ovObbObb(oa, asObb(B)); }
+		case 28: return ovObbObb(asObb(A), asObb(B));
+		default: break;
+	}
+	SupShapes sh; Obb o; GjkSimplex sx;
+	if (key % 6 == 5) { gjkOperands<1>(key, A, B, hullInfo, hullVerts, sh, o); return gjkPair<1>(sh, sx); } // x vs hull
+	if (key == 9 || key == 10 || key == 14 || key == 15 || key == 16) { gjkOperands<0>(key, A, B, hullInfo, hullVerts, sh, o); return gjkPair<0>(sh, sx); } // no closed form for parallel cylinders here (:790-797)
+	return false;
+}
+
+__global__ void __launch_bounds__(64) k_zone_overlap(u32* __restrict__ counters, const u64* __restrict__ pairSorted, const ColliderRec* __restrict__ colWorld,
+	const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts, u32 nb, u32* __restrict__ fieldMask, u32 fieldWords, PairSetView triggers, EventSink sink)
+{
+	u32 slot = counters[CTR_BUCKET_START + KEY_ZONE] + blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot >= counters[CTR_BUCKET_START + KEY_INVALID]) return;
+	u64 packed = pairSorted[slot];
+	ColliderRec A = colWorld[(u32)packed], B = colWorld[(u32)(packed >> 32)];
+	if (!overlapColliders(colType(A) * 6 + colType(B), A, B, hullInfo, hullVerts)) return;
+	bool zoneIsA = (__float_as_uint(A.d.w) & 0xFFu) != 0;
+	u32 flags = __float_as_uint(zoneIsA ? A.d.w : B.d.w);
+	u32 body = colBody(zoneIsA ? B : A), zoneType = flags & 0xFFu, zoneIndex = flags >> 8;
+	if (body >= nb) return;
+	if (zoneType == 2u) { if (fieldWords) atomicOr(&fieldMask[(size_t)body * fieldWords + (zoneIndex >> 5)], 1u << (zoneIndex & 31u)); }
+	else if (triggers.cur)
+	{
+		u64 key = ((u64)zoneIndex << 32) | body;
+		if (pairSetInsert(triggers.cur, triggers.mask, triggers.shift, key, counters) && !pairSetContains(triggers.prev, triggers.mask, triggers.shift, key))
+			eventWritePlain(sink, EVENT_TRIGGER_ENTER, zoneIndex, body, 0xFFFFFFFFu, body);
+	}
+}
+
 void launch_narrowphase(World& w, u32 numPairs)
 {
 	if (!numPairs) return;
@@ -1099,4 +1203,11 @@ void launch_narrowphase(World& w, u32 numPairs)
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epa<0>), dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
 	if (!w.hulls.empty())
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epa<1>), dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
+	if (!w.fields.empty() || !w.triggers.empty())
+	{
+		PairSetView tv = { w.triggers.empty() ? nullptr : w.triggerSet[w.triggerCur].p, w.triggers.empty() ? nullptr : w.triggerSet[w.triggerCur ^ 1].p, w.triggerSetSize - 1, 64u - (u32)__builtin_ctz(w.triggerSetSize ? w.triggerSetSize : 2u) };
+		EventSink sink = { (EventRec*)w.eventRing.p, w.dCounters.p, w.eventCap, w.stats.numInternalSteps };
+		hipLaunchKernelGGL(k_zone_overlap, dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, sortedPairs, w.colWorld.p, w.hullInfo.p, w.hullVerts.p, w.nb,
+			w.fieldMask.p, w.fieldWords, tv, sink);
+	}
 }

@@ -82,6 +82,8 @@ enum
 	CTR_REGION_CUTS = 400,  // 7 floats: region r holds bodies with cuts[r-1] <= x < cuts[r]
 	CTR_REGION_RANGE = 408, // 2 floats: [lo, hi] of the histogram that produces the next cuts
 	CTR_REGION_MINMAX = 410,// 2 words: running min / max of x (order-preserving integer encoding) for the next range
+	CTR_EVENT_COUNT = 416,  // append cursor of the event ring (trigger enter/leave, collision begin/end), reset by mi_drain_events
+	CTR_EVENT_OVERFLOW = 417,// bit 0: the event ring was full, events were dropped; bit 1: a pair-set table was full
 	CTR_WORDS = 512,
 };
 #define MI_NUM_SCHEDULE_KEYS ((MI_MAX_COLORS + 1) * 4)
@@ -94,7 +96,12 @@ struct World
 
 	// ---- host mirrors (add API) ----
 	struct HBody { float pos[3], rot[4]; float localCOG[3], invMass, invInertia[9]; float gravityFactor, linDamp, angDamp; float v[3], w[3], force[3], torque[3]; std::vector<u32> colliders; bool removed = false; };
-	struct HCollider { float shape[10]; float restitution, friction, density; u32 type, body; float spos[3], srot[4]; };
+	struct HCollider { float shape[10]; float restitution, friction, density; u32 type, body; float spos[3], srot[4]; u32 zoneType, zoneIndex; }; // zoneType: 0 none, 2 force field, 3 trigger (physics_object_type, physics.h:49-57)
+	struct HField { float force[3]; float pos[3], rot[4]; u32 hasTransform, numColliders; };   // force_field_component (physics.h:182-185) + the entity's transform
+	struct HTrigger { float pos[3], rot[4]; u32 numColliders; };                                 // trigger_component (physics.h:200-203); the callback becomes mi_drain_events
+	std::vector<HField> fields; std::vector<HTrigger> triggers;
+	bool fieldsDirty = true;              // a force changed: re-upload the per-field world-space forces
+	bool collisionBeginEvents = false, collisionEndEvents = false;
 	std::vector<HBody> bodies;
 	std::vector<HCollider> colliders;
 	struct HHull { std::vector<float> vertices; std::vector<u32> triangles; float aabbMin[3], aabbMax[3]; }; // bounding_hull_geometry (bounding_volumes.h:208-218)
@@ -139,6 +146,15 @@ struct World
 	DevBuf<float4> velBackup; bool flowPending = false; float pendingDt = 0.f; u32 pendingIters = 0, flowCooldown = 0, flowTestAbortStep = ~0u;
 	void recoverFlow(); int resolvePendingFlow();
 	u32 flowHopTicks = 100, flowBackoffCap = 64, flowPredictFrac = 192; // poll pacing: 10 ns ticks; fraction (/256) of the iteration period slept through (MI_FLOW_HOP / _CAP / _PREDICT)
+	// force fields, triggers, events
+	DevBuf<float4> fieldForce;            // per field: world-space force (localized fields only; global ones are summed on the host into globalForce)
+	DevBuf<u32> fieldMask; u32 fieldWords = 0; // per body: bit f set = inside localized field f this step (set by k_zone_overlap, consumed + cleared by k_apply_fields)
+	float globalForce[3] = { 0.f, 0.f, 0.f }; bool anyGlobalForce = false;
+	DevBuf<u64> triggerSet[2], collisionSet[2]; u32 triggerSetSize = 0, collisionSetSize = 0, triggerCur = 0, collisionCur = 0;
+	DevBuf<uint8_t> eventRing; u32 eventCap = 1u << 16;
+	std::vector<u64> restoredTriggerKeys, restoredCollisionKeys; // mi_world_restore: the snapshot's previous-step sets, entered when the first step sizes the tables
+	std::vector<mi_event> pendingEvents;  // drained from the device, not yet handed to the caller
+	void uploadFields(); void ensureEventBuffers(u32 numPairs);
 	DevBuf<uint8_t> tempStorage;
 	DevBuf<u32> sortHist;                 // counting sort: per-tile bucket histograms + their scan
 	DevBuf<u32> dCounters; u32* hCounters = nullptr; // CTR_WORDS words each
@@ -191,6 +207,9 @@ void launch_broadphase_count(World& w);                    // grid build + pair 
 void launch_broadphase_write(World& w, u32 numPairs);
 void launch_narrowphase(World& w, u32 numPairs);
 void launch_integrate_forces(World& w, float dt);
+void launch_apply_fields(World& w);                        // localized + global force fields -> force accumulators (before the force integration)
+void launch_trigger_events(World& w);                      // leave events + table hand-over of the trigger overlap set (after the narrowphase)
+void launch_collision_events(World& w, u32 numPairs);      // begin / end events of this step's manifolds (after the force integration)
 void launch_coloring(World& w, u32 numPairs);
 void launch_contact_init(World& w, u32 numPairs, float dt);
 void launch_solve_contacts_iteration(World& w, const u32* gridBlocks, u32 numColors, u32 firstTail, bool serialBucket);

@@ -303,7 +303,7 @@ void World::upload()
 		r.b = make_float4(c.shape[4], c.shape[5], c.shape[6], c.shape[7]);
 		r.c = make_float4(c.shape[8], c.shape[9], c.restitution, c.friction);
 		u32 body = (c.body == MI_STATIC_BODY) ? newNb : c.body;
-		r.d = make_float4(mi_u2f(c.type), mi_u2f(body), c.density, 0.f);
+		r.d = make_float4(mi_u2f(c.type), mi_u2f(body), c.density, mi_u2f(c.zoneType | (c.zoneIndex << 8))); // flags: force-field / trigger collider
 		hc[i] = r;
 		hsp[2 * i] = make_float4(c.spos[0], c.spos[1], c.spos[2], 0.f);
 		hsp[2 * i + 1] = make_float4(c.srot[0], c.srot[1], c.srot[2], c.srot[3]);
@@ -337,6 +337,7 @@ void World::upload()
 		MI_CHECK(hipMemcpyAsync(simMask.p, alive.data(), nb1, hipMemcpyHostToDevice, stream));
 		MI_CHECK(hipStreamSynchronize(stream)); // `alive` goes out of scope
 	}
+	fieldsDirty = true; // (re)sizes the per-body field bits
 	size_t ncap = std::max<size_t>(nc, 1);
 	colLocal.ensure(ncap, stream); colWorld.ensure(ncap, stream); colStaticPose.ensure(2 * ncap, stream); aabbMin.ensure(ncap, stream); aabbMax.ensure(ncap, stream);
 	hashKey.ensure(ncap, stream); hashKeySorted.ensure(ncap, stream); sortIdx.ensure(ncap, stream); sortIdxSorted.ensure(ncap, stream);
@@ -631,14 +632,18 @@ int World::stepInternal(float dt, u32 iters)
 	u32 prevColors = stats.numInternalSteps ? stats.numColors : 0xFFFFu;
 	u32 numPairs = hCounters[CTR_NUM_PAIRS];
 	ensurePairBuffers(*this, numPairs);
+	ensureEventBuffers(numPairs);
 	launch_broadphase_write(*this, numPairs);
 	if (T) MI_CHECK(hipEventRecord(ev[1], stream));
 
 	launch_narrowphase(*this, numPairs);
+	launch_trigger_events(*this);                          // physics.cpp:1255 (handleNonCollisionInteractions)
 	if (T) MI_CHECK(hipEventRecord(ev[2], stream));
 
 	flow_choose_regions(*this);
+	launch_apply_fields(*this);                            // :963-967, :1273
 	launch_integrate_forces(*this, dt);
+	launch_collision_events(*this, numPairs);              // :1284 (handleCollisionCallbacks: after the force integration)
 	launch_coloring(*this, numPairs);
 	launch_contact_init(*this, numPairs, dt);
 	launch_joint_init(*this, dt);
@@ -703,6 +708,93 @@ int World::stepInternal(float dt, u32 iters)
 	return lastError;
 }
 
+
+// ---- force fields / events: host side ------------------------------------------------------------------------------
+static V3 fieldForceWorld(const World::HField& f) // physics.cpp:767-771
+{
+	V3 force = v3(f.force[0], f.force[1], f.force[2]);
+	return f.hasTransform ? (q4(f.rot[0], f.rot[1], f.rot[2], f.rot[3]) * force) : force;
+}
+void World::uploadFields()
+{
+	if (!fieldsDirty) return;
+	fieldsDirty = false;
+	std::vector<float4> hf(std::max<size_t>(fields.size(), 1), make_float4(0.f, 0.f, 0.f, 0.f));
+	V3 sum = v3s(0.f); anyGlobalForce = false; bool anyLocal = false;
+	for (size_t i = fields.size(); i-- > 0;) // getForceFieldStates (physics.cpp:759-787): EnTT walks newest first
+	{
+		V3 f = fieldForceWorld(fields[i]);
+		if (fields[i].numColliders) { hf[i] = make_float4(f.x, f.y, f.z, 0.f); anyLocal = true; }
+		else { sum = sum + f; anyGlobalForce = true; }
+	}
+	globalForce[0] = sum.x; globalForce[1] = sum.y; globalForce[2] = sum.z;
+	u32 words = anyLocal ? ((u32)fields.size() + 31u) / 32u : 0u;
+	fieldForce.ensure(hf.size(), stream);
+	MI_CHECK(hipMemcpyAsync(fieldForce.p, hf.data(), sizeof(float4) * hf.size(), hipMemcpyHostToDevice, stream));
+	size_t maskWords = std::max<size_t>((size_t)words * ((size_t)nb + 1), 1);
+	if (words != fieldWords || maskWords > fieldMask.cap)
+	{
+		fieldWords = words;
+		fieldMask.ensure(maskWords, stream);
+		MI_CHECK(hipMemsetAsync(fieldMask.p, 0, sizeof(u32) * maskWords, stream)); // bits are set by k_zone_overlap and cleared by k_apply_fields
+	}
+	MI_CHECK(hipStreamSynchronize(stream)); // `hf` goes out of scope
+}
+
+static u32 pairSetSlot(u64 key, u32 size) { return (u32)((key * 0x9E3779B97F4A7C15ull) >> (64u - (u32)__builtin_ctz(size))); } // = pairSetHash (events.h)
+// Gives both tables of a pair set `newSize` slots; the previous step's keys (tables[cur ^ 1]) move over.
+static void resizePairSet(World& w, DevBuf<u64>* tables, u32& size, u32 cur, u32 newSize, std::vector<u64>* seed = nullptr)
+{
+	std::vector<u64> image(newSize, ~0ull);
+	if (seed)
+	{
+		for (u64 key : *seed) { u32 h = pairSetSlot(key, newSize); while (image[h] != ~0ull) h = (h + 1) & (newSize - 1); image[h] = key; }
+		seed->clear();
+	}
+	if (size)
+	{
+		std::vector<u64> old(size);
+		MI_CHECK(hipMemcpyAsync(old.data(), tables[cur ^ 1].p, sizeof(u64) * size, hipMemcpyDeviceToHost, w.stream));
+		MI_CHECK(hipStreamSynchronize(w.stream));
+		for (u64 key : old)
+		{
+			if (key == ~0ull) continue;
+			u32 h = pairSetSlot(key, newSize);
+			while (image[h] != ~0ull) h = (h + 1) & (newSize - 1);
+			image[h] = key;
+		}
+	}
+	tables[0].ensure(newSize, w.stream); tables[1].ensure(newSize, w.stream);
+	MI_CHECK(hipMemsetAsync(tables[cur].p, 0xFF, sizeof(u64) * newSize, w.stream));
+	MI_CHECK(hipMemcpyAsync(tables[cur ^ 1].p, image.data(), sizeof(u64) * newSize, hipMemcpyHostToDevice, w.stream));
+	MI_CHECK(hipStreamSynchronize(w.stream));
+	size = newSize;
+}
+void World::ensureEventBuffers(u32 numPairs)
+{
+	bool collisions = collisionBeginEvents || collisionEndEvents;
+	if (triggers.empty() && !collisions && fields.empty()) return;
+	if (!fields.empty()) uploadFields(); // the narrowphase's overlap kernel needs the per-body field bits
+	if (!eventRing.p)
+	{
+		if (const char* e = getenv("MI_EVENT_CAPACITY")) eventCap = std::max(16, atoi(e));
+		eventRing.ensure((size_t)eventCap * sizeof(mi_event), stream);
+	}
+	if (!triggers.empty())
+	{
+		u32 want = std::max(4096u, nextPow2(4u * std::max(nb, 1u)));
+		if (hCounters[CTR_EVENT_OVERFLOW] & 2u) want = std::max(want, triggerSetSize * 4u); // a table was full last step
+		want = std::max(want, nextPow2(4u * (u32)restoredTriggerKeys.size()));
+		if (want > triggerSetSize) resizePairSet(*this, triggerSet, triggerSetSize, triggerCur, want, &restoredTriggerKeys);
+	}
+	if (collisions)
+	{
+		u32 want = std::max(4096u, nextPow2(2u * std::max(numPairs, lastNumManifolds * 2u)));
+		want = std::max(want, nextPow2(4u * (u32)restoredCollisionKeys.size()));
+		if (want > collisionSetSize) resizePairSet(*this, collisionSet, collisionSetSize, collisionCur, want, &restoredCollisionKeys);
+	}
+}
+
 // physicsStep — reference physics.cpp:1364-1413
 int World::step(float* timer, const mi_physics_settings* s, float dt)
 {
@@ -746,7 +838,7 @@ struct mi_world { World w; mi_world(int dev) : w(dev) {} };
 
 namespace
 {
-	const uint32_t SNAPSHOT_MAGIC = 0x4850494Du, SNAPSHOT_VERSION = 1;
+	const uint32_t SNAPSHOT_MAGIC = 0x4850494Du, SNAPSHOT_VERSION = 2;
 	struct BlobWriter
 	{
 		std::vector<uint8_t> bytes;
@@ -761,6 +853,18 @@ namespace
 		template <typename T> void pod(T& v) { get(&v, sizeof(T)); }
 		template <typename T> void vec(std::vector<T>& v) { uint64_t n = 0; pod(n); if (!ok || n * sizeof(T) > left) { ok = false; return; } v.resize((size_t)n); if (n) get(v.data(), (size_t)n * sizeof(T)); }
 	};
+	std::vector<u64> previousKeys(World& w, DevBuf<u64>* tables, u32 size, u32 cur) // keys of the set the next step diffs against
+	{
+		std::vector<u64> keys;
+		if (!size) return keys;
+		std::vector<u64> image(size);
+		w.resolvePendingFlow();
+		MI_CHECK(hipMemcpyAsync(image.data(), tables[cur ^ 1].p, sizeof(u64) * size, hipMemcpyDeviceToHost, w.stream));
+		MI_CHECK(hipStreamSynchronize(w.stream));
+		for (u64 k : image) if (k != ~0ull) keys.push_back(k);
+		std::sort(keys.begin(), keys.end());
+		return keys;
+	}
 	struct BodyPod { float pos[3], rot[4], localCOG[3], invMass, invInertia[9], gravityFactor, linDamp, angDamp, v[3], w[3], force[3], torque[3]; uint32_t removed; };
 	void serialize(World& w, BlobWriter& out)
 	{
@@ -781,6 +885,10 @@ namespace
 		for (const World::HCollider& c : w.colliders) out.pod(c);
 		for (const World::HHull& h : w.hulls) { out.vec(h.vertices); out.vec(h.triangles); out.put(h.aabbMin, 12); out.put(h.aabbMax, 12); }
 		for (const JointSet& js : w.joints) { out.vec(js.pods); out.vec(js.a); out.vec(js.b); out.vec(js.alive); }
+		// force fields, triggers, and the previous step's overlap / collision sets (so that the next step raises the same events)
+		out.vec(w.fields); out.vec(w.triggers);
+		uint32_t flags = (w.collisionBeginEvents ? 1u : 0u) | (w.collisionEndEvents ? 2u : 0u); out.pod(flags);
+		out.vec(previousKeys(w, w.triggerSet, w.triggerSetSize, w.triggerCur)); out.vec(previousKeys(w, w.collisionSet, w.collisionSetSize, w.collisionCur));
 	}
 }
 
@@ -843,8 +951,12 @@ mi_world* mi_world_restore(const mi_world_desc* desc, const void* buffer, uint64
 	for (uint64_t i = 0; in.ok && i < nc; ++i) { World::HCollider c; in.pod(c); w.colliders.push_back(c); }
 	for (uint64_t i = 0; in.ok && i < nh; ++i) { World::HHull h; in.vec(h.vertices); in.vec(h.triangles); in.get(h.aabbMin, 12); in.get(h.aabbMax, 12); w.hulls.push_back(h); }
 	for (JointSet& js : w.joints) { in.vec(js.pods); in.vec(js.a); in.vec(js.b); in.vec(js.alive); }
+	std::vector<u64> triggerKeys, collisionKeys; uint32_t flags = 0;
+	in.vec(w.fields); in.vec(w.triggers); in.pod(flags); in.vec(triggerKeys); in.vec(collisionKeys);
 	if (!in.ok) { g_createError = "mi_world_restore: truncated snapshot"; delete world; return nullptr; }
-	w.topologyDirty = true; w.jointsDirty = true;
+	w.collisionBeginEvents = (flags & 1u) != 0; w.collisionEndEvents = (flags & 2u) != 0;
+	w.topologyDirty = true; w.jointsDirty = true; w.fieldsDirty = true;
+	w.restoredTriggerKeys = triggerKeys; w.restoredCollisionKeys = collisionKeys; // entered into the sets when the first step sizes them
 	return world;
 }
 const char* mi_last_error(mi_world* world) { return world ? world->w.lastErrorText.c_str() : g_createError.c_str(); }
@@ -909,6 +1021,105 @@ uint32_t mi_add_static_collider(mi_world* world, uint32_t type, const float* sha
 {
 	CHECK_WORLD(0xFFFFFFFFu);
 	return addCollider(W, MI_STATIC_BODY, type, shape, material, pos, rot);
+}
+
+
+// ---- force fields, triggers, events (physics.h:182-203, 356-380; physics.cpp:759-787, 952-1178) ----
+static void setPose(float* pos, float* rot, const float* p, const float* r)
+{
+	pos[0] = pos[1] = pos[2] = 0.f; rot[0] = rot[1] = rot[2] = 0.f; rot[3] = 1.f;
+	if (p) memcpy(pos, p, 12);
+	if (r) memcpy(rot, r, 16);
+}
+uint32_t mi_add_force_field(mi_world* world, const float force[3], const float pos[3], const float rot[4])
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	if (!force) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_force_field: force is NULL"); return 0xFFFFFFFFu; }
+	if (W->fields.size() >= (1u << 24)) { W->fail(MI_ERR_CAPACITY, "mi_add_force_field: too many fields"); return 0xFFFFFFFFu; }
+	World::HField f; memset(&f, 0, sizeof(f));
+	memcpy(f.force, force, 12); setPose(f.pos, f.rot, pos, rot); f.hasTransform = (pos || rot) ? 1u : 0u;
+	W->fields.push_back(f); W->fieldsDirty = true;
+	return (uint32_t)W->fields.size() - 1;
+}
+int mi_set_force_field(mi_world* world, uint32_t field, const float force[3])
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (field >= W->fields.size() || !force) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_set_force_field: field out of range"); return W->lastError; }
+	memcpy(W->fields[field].force, force, 12); W->fieldsDirty = true;
+	return MI_OK;
+}
+uint32_t mi_add_trigger(mi_world* world, const float pos[3], const float rot[4])
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	if (W->triggers.size() >= (1u << 24)) { W->fail(MI_ERR_CAPACITY, "mi_add_trigger: too many triggers"); return 0xFFFFFFFFu; }
+	World::HTrigger t; memset(&t, 0, sizeof(t)); setPose(t.pos, t.rot, pos, rot);
+	W->triggers.push_back(t);
+	return (uint32_t)W->triggers.size() - 1;
+}
+static uint32_t addZoneCollider(World* w, u32 zoneType, u32 zoneIndex, const float* pos, const float* rot, uint32_t type, const float* shape)
+{
+	mi_material none = { 0.f, 0.f, 0.f };
+	uint32_t id = addCollider(w, MI_STATIC_BODY, type, shape, &none, pos, rot);
+	if (id != 0xFFFFFFFFu) { w->colliders[id].zoneType = zoneType; w->colliders[id].zoneIndex = zoneIndex; }
+	return id;
+}
+uint32_t mi_add_force_field_collider(mi_world* world, uint32_t field, uint32_t type, const float* shape)
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	if (field >= W->fields.size() || !shape) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_force_field_collider: field out of range"); return 0xFFFFFFFFu; }
+	World::HField& f = W->fields[field];
+	uint32_t id = addZoneCollider(W, 2u, field, f.pos, f.rot, type, shape);
+	if (id != 0xFFFFFFFFu) { f.numColliders++; W->fieldsDirty = true; }
+	return id;
+}
+uint32_t mi_add_trigger_collider(mi_world* world, uint32_t trigger, uint32_t type, const float* shape)
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	if (trigger >= W->triggers.size() || !shape) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_trigger_collider: trigger out of range"); return 0xFFFFFFFFu; }
+	World::HTrigger& t = W->triggers[trigger];
+	uint32_t id = addZoneCollider(W, 3u, trigger, t.pos, t.rot, type, shape);
+	if (id != 0xFFFFFFFFu) t.numColliders++;
+	return id;
+}
+int mi_enable_collision_events(mi_world* world, int begin, int end)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->collisionBeginEvents = begin != 0; W->collisionEndEvents = end != 0;
+	return MI_OK;
+}
+uint32_t mi_drain_events(mi_world* world, mi_event* out, uint32_t capacity)
+{
+	CHECK_WORLD(0);
+	if (W->eventRing.p)
+	{
+		u32 head[2] = { 0, 0 };
+		MI_CHECK(hipMemcpyAsync(head, W->dCounters.p + CTR_EVENT_COUNT, sizeof(head), hipMemcpyDeviceToHost, W->stream));
+		MI_CHECK(hipStreamSynchronize(W->stream));
+		u32 n = std::min(head[0], W->eventCap);
+		if (n)
+		{
+			size_t first = W->pendingEvents.size();
+			W->pendingEvents.resize(first + n);
+			MI_CHECK(hipMemcpyAsync(W->pendingEvents.data() + first, W->eventRing.p, sizeof(mi_event) * n, hipMemcpyDeviceToHost, W->stream));
+			MI_CHECK(hipStreamSynchronize(W->stream));
+			// the order the reference's merge loops call back in: per step the trigger events, then the collision events, each by pair
+			std::sort(W->pendingEvents.begin() + first, W->pendingEvents.end(), [](const mi_event& x, const mi_event& y)
+			{
+				if (x.step != y.step) return x.step < y.step;
+				u32 cx = x.kind >> 1, cy = y.kind >> 1;
+				if (cx != cy) return cx < cy;
+				if (x.a != y.a) return x.a < y.a;
+				return x.b < y.b;
+			});
+		}
+		if (head[0] || head[1]) MI_CHECK(hipMemsetAsync(W->dCounters.p + CTR_EVENT_COUNT, 0, sizeof(head), W->stream));
+		if (head[1] & 1u) W->fail(MI_ERR_CAPACITY, "the event ring overflowed: events were lost (drain more often or raise MI_EVENT_CAPACITY)");
+		if (head[1] & 2u) W->hCounters[CTR_EVENT_OVERFLOW] |= 2u; // ensureEventBuffers grows the table
+	}
+	uint32_t n = (uint32_t)std::min<size_t>(capacity, W->pendingEvents.size());
+	if (n && out) memcpy(out, W->pendingEvents.data(), sizeof(mi_event) * n);
+	W->pendingEvents.erase(W->pendingEvents.begin(), W->pendingEvents.begin() + n);
+	return n;
 }
 
 // ---- constraints (physics.cpp:128-333) ----

@@ -53,6 +53,9 @@ class Scene:
         self.colliders = []   # (body or STATIC, type, shape[<=10], material3, static_pos3, static_rot4)
         self.joints = []      # ("hinge"|"cone_twist"|..., a, b, args...)
         self.hulls = []       # convex hull geometries: (vertices [n,3], triangles [m,3]); HULL colliders refer to them by index
+        self.fields = []      # force fields: (force3, pos3 or None, rot4 or None, [(type, shape), ...]); no colliders = global
+        self.triggers = []    # triggers: (pos3 or None, rot4 or None, [(type, shape), ...])
+        self.collision_events = False
 
     def add_body(self, pos, rot=(0, 0, 0, 1), kinematic=False, gravity_factor=1.0, linear_damping=0.4, angular_damping=0.4):
         self.bodies.append((tuple(float(x) for x in pos), tuple(float(x) for x in rot), kinematic, gravity_factor, linear_damping, angular_damping))
@@ -65,6 +68,14 @@ class Scene:
     def add_hull_geometry(self, vertices, triangles):
         self.hulls.append((np.asarray(vertices, np.float32).reshape(-1, 3), np.asarray(triangles, np.uint32).reshape(-1, 3)))
         return len(self.hulls) - 1
+
+    def add_force_field(self, force, pos=None, rot=None, colliders=()):
+        self.fields.append((tuple(force), pos, rot, list(colliders)))
+        return len(self.fields) - 1
+
+    def add_trigger(self, pos=None, rot=None, colliders=()):
+        self.triggers.append((pos, rot, list(colliders)))
+        return len(self.triggers) - 1
 
     def add_joint(self, kind, a, b, *args):
         self.joints.append((kind, a, b) + args)
@@ -86,6 +97,16 @@ class Scene:
         for j in self.joints:
             kind, a, b, args = j[0], j[1], j[2], j[3:]
             getattr(world, "add_%s_constraint_global" % kind)(a, b, *args)
+        for force, pos, rot, cols in self.fields:
+            f = world.add_force_field(force, pos, rot)
+            for ctype, shape in cols:
+                world.add_force_field_collider(f, ctype, shape)
+        for pos, rot, cols in self.triggers:
+            t = world.add_trigger(pos, rot)
+            for ctype, shape in cols:
+                world.add_trigger_collider(t, ctype, shape)
+        if self.collision_events:
+            world.enable_collision_events(True, True)
         return world
 
 
@@ -253,6 +274,28 @@ def all_shapes_hull(n=490, seed=55120931, column_height=7, pitch=1.7, layer=1.6)
 
 
 # ---- humanoid ragdoll (reference src/physics/ragdoll.cpp:10-123) ------------------------------------------
+def zones(n=420, seed=7741093):
+    """all_shapes_hull under force fields and triggers: an updraft column (sphere), a rotated side-wind slab (OBB through the field
+    entity's rotation), a capsule- and a cylinder-shaped field, a hull-shaped trigger, a two-collider trigger (AABB + sphere that
+    overlap: one event per body), two global fields (wind + a little extra gravity) and collision begin / end events.  Every boolean
+    overlap test of the 21 type pairs is reached (rigid-body shapes x zone shapes)."""
+    s = all_shapes_hull(n=n, seed=seed)
+    s.name = "zones_%d" % n
+    oct_geo = s.add_hull_geometry(*hull_octahedron(2.5))
+    q = _quat_axis_angle((0.0, 0.0, 1.0), 0.5)
+    s.add_force_field((0.0, 60.0, 0.0), pos=(0.0, 0.0, 0.0), colliders=[(SPHERE, (1.0, 2.5, 1.0, 2.5))])
+    s.add_force_field((25.0, 0.0, 0.0), pos=(-2.0, 1.0, 0.0), rot=q, colliders=[(OBB, (0.0, 0.0, 0.38268343, 0.92387953, 0.0, 1.0, 0.0, 3.0, 0.6, 3.0))])
+    s.add_force_field((0.0, 0.0, 3.0))                       # global wind
+    s.add_force_field((0.0, 0.0, -40.0), pos=(3.0, 0.0, 3.0), colliders=[(CAPSULE, (0.0, 0.5, 0.0, 0.0, 3.5, 0.0, 1.2))])
+    s.add_force_field((-30.0, 10.0, 0.0), pos=(-3.0, 0.0, -3.0), colliders=[(CYLINDER, (0.0, 0.2, 0.0, 1.0, 3.0, 0.5, 1.4)), (AABB, (-1.0, 0.0, -1.0, 1.0, 1.0, 1.0))])
+    s.add_force_field((0.0, -0.5, 0.0), rot=q)               # global, rotated by its entity
+    s.add_trigger(pos=(2.0, 2.0, -2.0), rot=q, colliders=[(HULL, (0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, float(oct_geo)))])
+    s.add_trigger(colliders=[(AABB, (-6.0, 0.0, -1.0, 6.0, 1.5, 1.0)), (SPHERE, (0.0, 1.0, 0.0, 1.5))])
+    s.add_trigger(pos=(0.0, 4.0, 0.0), colliders=[(CAPSULE, (-3.0, 0.0, 0.0, 3.0, 0.0, 0.0, 0.8)), (CYLINDER, (0.0, 0.0, -3.0, 0.0, 0.0, 3.0, 0.8)), (OBB, (0.0, 0.38268343, 0.0, 0.92387953, 0.0, 2.0, 0.0, 2.0, 0.3, 2.0))])
+    s.collision_events = True
+    return s
+
+
 def _quat_axis_angle(axis, angle):
     h = np.float32(angle) * np.float32(0.5)
     s = np.float32(math.sin(h))
@@ -386,4 +429,6 @@ def by_name(name):
         return all_shapes()
     if name == "shapes_hull":
         return all_shapes_hull()
+    if name == "zones":
+        return zones()
     raise KeyError(name)

@@ -119,6 +119,34 @@ int mi_delete_all_constraints_from_body(mi_world* w, uint32_t body);  /* deleteA
  * collision_broad.cpp:42-75).  Indices are add-order positions and stay valid; the body is switched off for good. */
 int mi_delete_body(mi_world* w, uint32_t body);
 
+/* ---- force fields, triggers, collision events (row N2 of SURVEY §8f) --------------------------------------------------------------
+ * force_field_component (physics.h:182-185): `force` is rotated by the entity's transform when it has one (pass pos/rot, or NULL for
+ * none; physics.cpp:767-771).  A field without colliders acts on every body (global, :782, :1273); a field with colliders acts on
+ * the rigid bodies whose colliders overlap them (:963-967).  A body inside several localized fields receives their forces in
+ * ascending field id.  Returns the field id. */
+uint32_t mi_add_force_field(mi_world* w, const float force[3], const float pos[3], const float rot[4]);
+int mi_set_force_field(mi_world* w, uint32_t field, const float force[3]);
+/* trigger_component (physics.h:200-203): the std::function callback becomes mi_drain_events.  Returns the trigger id. */
+uint32_t mi_add_trigger(mi_world* w, const float pos[3], const float rot[4]);
+/* Colliders of a force-field / trigger entity (collider_component on that entity, physics.cpp:657-666): shape payload as in
+ * mi_add_collider, in the entity's local space; no material.  Return the collider id. */
+uint32_t mi_add_force_field_collider(mi_world* w, uint32_t field, uint32_t type, const float* shape);
+uint32_t mi_add_trigger_collider(mi_world* w, uint32_t trigger, uint32_t type, const float* shape);
+/* physics_settings::collisionBeginCallback / collisionEndCallback (physics.h:394-395) set or not.  Enable before the first step:
+ * the previous step's collision set is only kept while one of the two is on. */
+int mi_enable_collision_events(mi_world* w, int begin, int end);
+/* trigger_event (physics.h:193-198), collision_begin_event / collision_end_event (physics.h:356-376) as one record.
+ * kind: MI_EVENT_*; step: internal step that raised it; trigger events: a = trigger id, b = bodyB = body id;
+ * collision events: a, b = collider ids in contact-normal order, bodyA / bodyB = their bodies (MI_STATIC_BODY for a static
+ * collider); begin events carry the mean contact point, mean normal and the relative velocity (B - A) at that point. */
+enum { MI_EVENT_TRIGGER_ENTER = 0, MI_EVENT_TRIGGER_LEAVE = 1, MI_EVENT_COLLISION_BEGIN = 2, MI_EVENT_COLLISION_END = 3 };
+typedef struct mi_event { uint32_t kind, step, a, b, bodyA, bodyB; float position[3], normal[3], relativeVelocity[3]; } mi_event;
+/* Copies out up to `capacity` pending events in the order the reference calls back in (per step: trigger events, then collision
+ * events, each sorted by pair) and returns how many; call again until it returns 0.  Synchronises with the device.
+ * If the device-side event ring overflowed since the last drain, mi_last_error() says so and the call after this one fails with
+ * MI_ERR_CAPACITY (events were lost). */
+uint32_t mi_drain_events(mi_world* w, mi_event* out, uint32_t capacity);
+
 /* void testPhysicsInteraction(game_scene&, ray, float strength = 1000.f): physics.h:404, physics.cpp:556-628 — the closest rigid-body
  * collider hit by the ray gets force = direction * strength at the hit point.  Returns 1 + the index of the body that was
  * pushed, 0 when the ray hits nothing (this one function does not return a status code). */

@@ -1138,4 +1138,174 @@ static inline bool intersectColliders(const collider_union& A, const collider_un
 	return false;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Boolean overlap tests for the non-collision interactions (force fields, triggers): overlapCheck,
+// collision_narrow.cpp:1593-1689, over bounding_volumes.h:301-363 and bounding_volumes.cpp:704-835, 1079-1244.
+// ---------------------------------------------------------------------------------------------------
+static inline bool sphereVsSphere(const bounding_sphere& a, const bounding_sphere& b) // bounding_volumes.h:301-307
+{
+	vec3 d = a.center - b.center;
+	float dist2 = dot(d, d);
+	float radiusSum = a.radius + b.radius;
+	return dist2 <= radiusSum * radiusSum;
+}
+static inline bool sphereVsCapsule(const bounding_sphere& s, const bounding_capsule& c) // :314-318
+{
+	vec3 closestPoint = closestPoint_PointSegment(s.center, line_segment{ c.positionA, c.positionB });
+	return sphereVsSphere(s, bounding_sphere{ closestPoint, c.radius });
+}
+static inline bool sphereVsCylinder(const bounding_sphere& s, const bounding_cylinder& c) // bounding_volumes.cpp:704-724
+{
+	vec3 ab = c.positionB - c.positionA;
+	float t = dot(s.center - c.positionA, ab) / squaredLength(ab);
+	if (t >= 0.f && t <= 1.f) { return sphereVsSphere(s, bounding_sphere{ lerp(c.positionA, c.positionB, t), c.radius }); }
+	vec3 p = (t <= 0.f) ? c.positionA : c.positionB;
+	vec3 up = (t <= 0.f) ? -ab : ab;
+	vec3 projectedDirToCenter = normalize(cross(cross(up, s.center - p), up));
+	vec3 endA = p + projectedDirToCenter * c.radius;
+	vec3 endB = p - projectedDirToCenter * c.radius;
+	vec3 closestToSphere = closestPoint_PointSegment(s.center, line_segment{ endA, endB });
+	float sqDistance = squaredLength(closestToSphere - s.center);
+	return sqDistance <= s.radius; // sic: the squared distance against the plain radius (:723)
+}
+static inline bool sphereVsAABB(const bounding_sphere& s, const bounding_box& a) // bounding_volumes.h:320-326
+{
+	vec3 p = closestPoint_PointAABB(s.center, a);
+	vec3 n = p - s.center;
+	float sqDistance = squaredLength(n);
+	return sqDistance <= s.radius * s.radius;
+}
+static inline bool sphereVsOBB(const bounding_sphere& s, const bounding_oriented_box& o) // :328-336
+{
+	bounding_box aabb = bounding_box::fromCenterRadius(o.center, o.radius);
+	bounding_sphere s_ = { conjugate(o.rotation) * (s.center - o.center) + o.center, s.radius };
+	return sphereVsAABB(s_, aabb);
+}
+static inline bool capsuleVsCapsule(const bounding_capsule& a, const bounding_capsule& b) // :338-343
+{
+	vec3 closestPoint1, closestPoint2;
+	closestPoint_SegmentSegment(line_segment{ a.positionA, a.positionB }, line_segment{ b.positionA, b.positionB }, closestPoint1, closestPoint2);
+	return sphereVsSphere(bounding_sphere{ closestPoint1, a.radius }, bounding_sphere{ closestPoint2, b.radius });
+}
+static inline bool capsuleVsCylinder(const bounding_capsule& a, const bounding_cylinder& b) // :345-350
+{
+	vec3 closestPoint1, closestPoint2;
+	closestPoint_SegmentSegment(line_segment{ a.positionA, a.positionB }, line_segment{ b.positionA, b.positionB }, closestPoint1, closestPoint2);
+	return sphereVsCylinder(bounding_sphere{ closestPoint1, a.radius }, b);
+}
+template <typename A, typename B> static inline bool gjkOverlap(const A& a, const B& b) { gjk_simplex simplex; return gjkIntersectionTest(a, b, simplex); }
+static inline bool capsuleVsAABB(const bounding_capsule& c, const bounding_box& b) { return gjkOverlap(capsule_support_fn{ c }, aabb_support_fn{ b }); } // bounding_volumes.cpp:742-749
+static inline bool capsuleVsOBB(const bounding_capsule& c, const bounding_oriented_box& o) // :751-760
+{
+	bounding_box aabb = bounding_box::fromCenterRadius(o.center, o.radius);
+	bounding_capsule c_ = { conjugate(o.rotation) * (c.positionA - o.center) + o.center, conjugate(o.rotation) * (c.positionB - o.center) + o.center, c.radius };
+	return capsuleVsAABB(c_, aabb);
+}
+static inline bool cylinderVsCylinder(const bounding_cylinder& a, const bounding_cylinder& b) { return gjkOverlap(cylinder_support_fn{ a }, cylinder_support_fn{ b }); } // :790-797
+static inline bool cylinderVsAABB(const bounding_cylinder& c, const bounding_box& b) { return gjkOverlap(cylinder_support_fn{ c }, aabb_support_fn{ b }); } // :799-806
+static inline bool cylinderVsOBB(const bounding_cylinder& c, const bounding_oriented_box& o) // :808-817
+{
+	bounding_box aabb = bounding_box::fromCenterRadius(o.center, o.radius);
+	bounding_cylinder c_ = { conjugate(o.rotation) * (c.positionA - o.center) + o.center, conjugate(o.rotation) * (c.positionB - o.center) + o.center, c.radius };
+	return cylinderVsAABB(c_, aabb);
+}
+// aabbVsAABB (bounding_volumes.h:352-358): oshapes.h
+static inline bool obbVsOBB(const bounding_oriented_box& a, const bounding_oriented_box& b) // bounding_volumes.cpp:1079-1199
+{
+	float ra, rb, penetration;
+	vec3 axesA[3] = { a.rotation * vec3(1.f, 0.f, 0.f), a.rotation * vec3(0.f, 1.f, 0.f), a.rotation * vec3(0.f, 0.f, 1.f) };
+	vec3 axesB[3] = { b.rotation * vec3(1.f, 0.f, 0.f), b.rotation * vec3(0.f, 1.f, 0.f), b.rotation * vec3(0.f, 0.f, 1.f) };
+	float r[3][3], absR[3][3]; // r[row][column] = dot(axesA[row], axesB[column])
+	for (u32 i = 0; i < 3; ++i) for (u32 j = 0; j < 3; ++j) { r[i][j] = dot(axesA[i], axesB[j]); absR[i][j] = fabsf(r[i][j]) + EPSILON; }
+	vec3 tw = b.center - a.center;
+	vec3 t = conjugate(a.rotation) * tw;
+	const float tA[3] = { t.x, t.y, t.z }, rA[3] = { a.radius.x, a.radius.y, a.radius.z }, rB[3] = { b.radius.x, b.radius.y, b.radius.z };
+	for (u32 i = 0; i < 3; ++i) // a's faces
+	{
+		ra = rA[i];
+		rb = dot(vec3(absR[i][0], absR[i][1], absR[i][2]), b.radius);
+		penetration = ra + rb - fabsf(tA[i]);
+		if (penetration < 0.f) { return false; }
+	}
+	for (u32 i = 0; i < 3; ++i) // b's faces
+	{
+		ra = dot(vec3(absR[0][i], absR[1][i], absR[2][i]), a.radius);
+		rb = rB[i];
+		float d = dot(vec3(r[0][i], r[1][i], r[2][i]), t);
+		penetration = ra + rb - fabsf(d);
+		if (penetration < 0.f) { return false; }
+	}
+#define ORC_EDGE(RA, RB, D) ra = (RA); rb = (RB); penetration = ra + rb - fabsf(D); if (penetration < 0.f) { return false; }
+	ORC_EDGE(rA[1] * absR[2][0] + rA[2] * absR[1][0], rB[1] * absR[0][2] + rB[2] * absR[0][1], t.z * r[1][0] - t.y * r[2][0]) // a.x x b.x
+	ORC_EDGE(rA[1] * absR[2][1] + rA[2] * absR[1][1], rB[0] * absR[0][2] + rB[2] * absR[0][0], t.z * r[1][1] - t.y * r[2][1]) // a.x x b.y
+	ORC_EDGE(rA[1] * absR[2][2] + rA[2] * absR[1][2], rB[0] * absR[0][1] + rB[1] * absR[0][0], t.z * r[1][2] - t.y * r[2][2]) // a.x x b.z
+	ORC_EDGE(rA[0] * absR[2][0] + rA[2] * absR[0][0], rB[1] * absR[1][2] + rB[2] * absR[1][1], t.x * r[2][0] - t.z * r[0][0]) // a.y x b.x
+	ORC_EDGE(rA[0] * absR[2][1] + rA[2] * absR[0][1], rB[0] * absR[1][2] + rB[2] * absR[1][0], t.x * r[2][1] - t.z * r[0][1]) // a.y x b.y
+	ORC_EDGE(rA[0] * absR[2][2] + rA[2] * absR[0][2], rB[0] * absR[1][1] + rB[1] * absR[1][0], t.x * r[2][2] - t.z * r[0][2]) // a.y x b.z
+	ORC_EDGE(rA[0] * absR[1][0] + rA[1] * absR[0][0], rB[1] * absR[2][2] + rB[2] * absR[2][1], t.y * r[0][0] - t.x * r[1][0]) // a.z x b.x
+	ORC_EDGE(rA[0] * absR[1][1] + rA[1] * absR[0][1], rB[0] * absR[2][2] + rB[2] * absR[2][0], t.y * r[0][1] - t.x * r[1][1]) // a.z x b.y
+	ORC_EDGE(rA[0] * absR[1][2] + rA[1] * absR[0][2], rB[0] * absR[2][1] + rB[1] * absR[2][0], t.y * r[0][2] - t.x * r[1][2]) // a.z x b.z
+#undef ORC_EDGE
+	return true;
+}
+static inline bool aabbVsOBB(const bounding_box& a, const bounding_oriented_box& o) // bounding_volumes.h:360-363
+{
+	return obbVsOBB(bounding_oriented_box{ quat(0.f, 0.f, 0.f, 1.f), a.getCenter(), a.getRadius() }, o);
+}
+template <typename A> static inline bool supportOverlapsHull(const A& a, const bounding_hull& h) { return gjkOverlap(a, hull_support_fn{ h }); } // bounding_volumes.cpp:726-733, 762-769, 819-835, 1201-1244
+
+// overlapCheck (collision_narrow.cpp:1593-1689) on (typeA <= typeB)
+static inline bool overlapColliders(const collider_union& A, const collider_union& B)
+{
+	switch (A.type)
+	{
+		case collider_type_sphere:
+			switch (B.type)
+			{
+				case collider_type_sphere: return sphereVsSphere(A.sphere(), B.sphere());
+				case collider_type_capsule: return sphereVsCapsule(A.sphere(), B.capsule());
+				case collider_type_cylinder: return sphereVsCylinder(A.sphere(), B.cylinder());
+				case collider_type_aabb: return sphereVsAABB(A.sphere(), B.aabb());
+				case collider_type_obb: return sphereVsOBB(A.sphere(), B.obb());
+				case collider_type_hull: return supportOverlapsHull(sphere_support_fn{ A.sphere() }, B.hull());
+			}
+			break;
+		case collider_type_capsule:
+			switch (B.type)
+			{
+				case collider_type_capsule: return capsuleVsCapsule(A.capsule(), B.capsule());
+				case collider_type_cylinder: return capsuleVsCylinder(A.capsule(), B.cylinder());
+				case collider_type_aabb: return capsuleVsAABB(A.capsule(), B.aabb());
+				case collider_type_obb: return capsuleVsOBB(A.capsule(), B.obb());
+				case collider_type_hull: return supportOverlapsHull(capsule_support_fn{ A.capsule() }, B.hull());
+			}
+			break;
+		case collider_type_cylinder:
+			switch (B.type)
+			{
+				case collider_type_cylinder: return cylinderVsCylinder(A.cylinder(), B.cylinder());
+				case collider_type_aabb: return cylinderVsAABB(A.cylinder(), B.aabb());
+				case collider_type_obb: return cylinderVsOBB(A.cylinder(), B.obb());
+				case collider_type_hull: return supportOverlapsHull(cylinder_support_fn{ A.cylinder() }, B.hull());
+			}
+			break;
+		case collider_type_aabb:
+			switch (B.type)
+			{
+				case collider_type_aabb: return aabbVsAABB(A.aabb(), B.aabb());
+				case collider_type_obb: return aabbVsOBB(A.aabb(), B.obb());
+				case collider_type_hull: return supportOverlapsHull(aabb_support_fn{ A.aabb() }, B.hull());
+			}
+			break;
+		case collider_type_obb:
+			if (B.type == collider_type_obb) return obbVsOBB(A.obb(), B.obb());
+			if (B.type == collider_type_hull) return supportOverlapsHull(obb_support_fn{ A.obb() }, B.hull());
+			break;
+		case collider_type_hull:
+			if (B.type == collider_type_hull) return supportOverlapsHull(hull_support_fn{ A.hull() }, B.hull());
+			break;
+	}
+	return false;
+}
+
 } // namespace orc

@@ -23,6 +23,11 @@ COLLIDER_DTYPE = np.dtype([("shape", "<f4", 10), ("restitution", "<f4"), ("frict
 CONTACT_DTYPE = np.dtype([("point", "<f4", 3), ("depth", "<f4"), ("normal", "<f4", 3), ("friction_restitution", "<u4")])
 RB_GLOBAL_DTYPE = np.dtype([("rotation", "<f4", 4), ("localCOG", "<f4", 3), ("position", "<f4", 3), ("invInertia", "<f4", 9),
                             ("invMass", "<f4"), ("v", "<f4", 3), ("w", "<f4", 3)])
+# trigger_event / collision_begin_event / collision_end_event as one record (same layout as mi_event, include/mi_physics.h)
+EVENT_DTYPE = np.dtype([("kind", "<u4"), ("step", "<u4"), ("a", "<u4"), ("b", "<u4"), ("bodyA", "<u4"), ("bodyB", "<u4"),
+                        ("position", "<f4", 3), ("normal", "<f4", 3), ("relativeVelocity", "<f4", 3)])
+TRIGGER_ENTER, TRIGGER_LEAVE, COLLISION_BEGIN, COLLISION_END = range(4)
+assert EVENT_DTYPE.itemsize == 60
 assert COLLIDER_DTYPE.itemsize == 64 and CONTACT_DTYPE.itemsize == 32 and RB_GLOBAL_DTYPE.itemsize == 104
 
 
@@ -59,7 +64,8 @@ def _lib(avx2=False):
                      "orc_add_fixed_constraint_global", "orc_add_hinge_constraint_global", "orc_add_cone_twist_constraint_global",
                      "orc_add_slider_constraint_global", "orc_num_bodies", "orc_num_colliders", "orc_num_pairs", "orc_num_contacts",
                      "orc_num_collisions", "orc_sorting_axis_used", "orc_sorting_axis_next", "orc_num_contact_slots",
-                     "orc_narrowphase_ordered", "orc_schedule", "orc_read_slot_counts", "orc_add_hull_geometry", "orc_test_physics_interaction"):
+                     "orc_narrowphase_ordered", "orc_schedule", "orc_read_slot_counts", "orc_add_hull_geometry", "orc_test_physics_interaction",
+                     "orc_add_force_field", "orc_add_trigger", "orc_add_force_field_collider", "orc_add_trigger_collider", "orc_drain_events"):
             getattr(lib, name).restype = C.c_uint32
         _libs[key] = lib
     return _libs[key]
@@ -105,6 +111,39 @@ class OracleWorld:
     def add_static_collider(self, ctype, shape, material, pos=(0, 0, 0), rot=(0, 0, 0, 1)):
         s = np.zeros(10, np.float32); s[:len(shape)] = shape
         return self.lib.orc_add_static_collider(self.w, C.c_uint32(ctype), _f(s), _f(material), _f(pos), _f(rot))
+
+    # ---- force fields, triggers, events (physics.h:182-203, 356-380; physics.cpp:759-787, 952-1178) ----
+    def add_force_field(self, force, pos=None, rot=None):
+        """A field without colliders acts on every body; with colliders, on the bodies overlapping them."""
+        return self.lib.orc_add_force_field(self.w, _f(force), _f(pos) if pos is not None else None, _f(rot) if rot is not None else None)
+
+    def set_force_field(self, field, force):
+        return self.lib.orc_set_force_field(self.w, C.c_uint32(field), _f(force))
+
+    def add_trigger(self, pos=None, rot=None):
+        return self.lib.orc_add_trigger(self.w, _f(pos) if pos is not None else None, _f(rot) if rot is not None else None)
+
+    def add_force_field_collider(self, field, ctype, shape):
+        s = np.zeros(10, np.float32); s[:len(shape)] = shape
+        return self.lib.orc_add_force_field_collider(self.w, C.c_uint32(field), C.c_uint32(ctype), _f(s))
+
+    def add_trigger_collider(self, trigger, ctype, shape):
+        s = np.zeros(10, np.float32); s[:len(shape)] = shape
+        return self.lib.orc_add_trigger_collider(self.w, C.c_uint32(trigger), C.c_uint32(ctype), _f(s))
+
+    def enable_collision_events(self, begin=True, end=True):
+        self.lib.orc_enable_collision_events(self.w, int(begin), int(end))
+
+    def zone_pair_stats(self):
+        """(tested[6,6], hit[6,6]): overlap checks by (typeA, typeB) since the world was created."""
+        t = np.zeros(36, np.uint32); h = np.zeros(36, np.uint32)
+        self.lib.orc_zone_pair_stats(self.w, _p(t), _p(h))
+        return t.reshape(6, 6), h.reshape(6, 6)
+
+    def drain_events(self, capacity=1 << 16):
+        out = np.zeros(capacity, EVENT_DTYPE)
+        n = self.lib.orc_drain_events(self.w, _p(out), C.c_uint32(capacity))
+        return out[:n]
 
     def add_distance_constraint_local(self, a, b, la, lb, distance):
         return self.lib.orc_add_distance_constraint_local(self.w, a, b, _f(la), _f(lb), C.c_float(distance))
@@ -261,6 +300,16 @@ def narrowphase_ordered(colliders, pairs):
     out = np.zeros(4 * len(pairs), CONTACT_DTYPE); counts = np.zeros(len(pairs), np.uint8)
     n = lib.orc_narrowphase_ordered(_p(colliders), _p(pairs), C.c_uint32(len(pairs)), _p(out), _p(counts))
     return out[:n], counts
+
+
+def overlap_ordered(colliders, pairs):
+    """Boolean overlapCheck (collision_narrow.cpp:1593-1689) for ORDERED collider pairs (typeA <= typeB).  Returns one flag per pair."""
+    lib = _lib()
+    colliders = np.ascontiguousarray(colliders, COLLIDER_DTYPE)
+    pairs = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+    out = np.zeros(len(pairs), np.uint8)
+    lib.orc_overlap_ordered(_p(colliders), _p(pairs), C.c_uint32(len(pairs)), _p(out))
+    return out.astype(bool)
 
 
 def schedule(body_pairs, dummy):

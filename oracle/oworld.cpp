@@ -33,8 +33,20 @@ struct collider
 {
 	collider_union local;  // shape in the parent's local space
 	u32 parent;            // body id or STATIC_BODY
-	trs staticTransform;   // transform of a static collider's entity
+	trs staticTransform;   // transform of a static collider's entity (or of the force field / trigger entity it belongs to)
+	u32 zoneType = physics_object_type_static_collider; // physics_object_type_force_field / _trigger: the collider of such an entity (physics.cpp:657-666)
+	u32 zoneIndex = 0;     // force field / trigger id
 };
+
+// force_field_component (physics.h:182-185) + its entity's optional transform_component
+struct force_field { vec3 force; bool hasTransform; trs transform; u32 numColliders; };
+// trigger_component (physics.h:200-203) without the callback: events are drained by the caller
+struct trigger { trs transform; u32 numColliders; };
+// trigger_event / collision_begin_event / collision_end_event (physics.h:187-198, 356-376) as one plain record; same layout as mi_event
+enum event_kind : u32 { event_trigger_enter = 0, event_trigger_leave = 1, event_collision_begin = 2, event_collision_end = 3 };
+struct event_record { u32 kind, step, a, b, bodyA, bodyB; float position[3], normal[3], relativeVelocity[3]; };
+struct entity_pair { u32 a, b; bool operator<(const entity_pair& o) const { return a < o.a || (a == o.a && b < o.b); } bool operator==(const entity_pair& o) const { return a == o.a && b == o.b; } };
+struct collision_entity_pair { u32 a, b, contactOffset, numContacts; bool operator<(const collision_entity_pair& o) const { return a < o.a || (a == o.a && b < o.b); } bool operator==(const collision_entity_pair& o) const { return a == o.a && b == o.b; } };
 
 struct sap_endpoint { float value; u32 collider; bool start; };
 
@@ -60,6 +72,16 @@ struct world
 	std::vector<hinge_constraint> hingeConstraints; std::vector<constraint_body_pair> hingePairs;
 	std::vector<cone_twist_constraint> coneTwistConstraints; std::vector<constraint_body_pair> coneTwistPairs;
 	std::vector<slider_constraint> sliderConstraints; std::vector<constraint_body_pair> sliderPairs;
+
+	// force fields, triggers, events (physics.cpp:759-787, 952-1178)
+	std::vector<force_field> forceFields;
+	std::vector<trigger> triggers;
+	std::vector<entity_pair> prevFrameTriggerOverlaps;              // event_context
+	std::vector<collision_entity_pair> prevFrameCollisions;
+	bool collisionBeginEvents = false, collisionEndEvents = false;  // physics_settings::collisionBeginCallback / collisionEndCallback set
+	std::vector<event_record> events;                               // callbacks in call order, drained by orc_drain_events
+	u32 stepIndex = 0;
+	u32 zoneTested[36] = {}, zoneHit[36] = {};                      // overlap checks per type pair (typeA * 6 + typeB), for test coverage reports
 
 	// sap_context (collision_broad.cpp:20-24)
 	std::vector<sap_endpoint> endpoints;
@@ -269,6 +291,7 @@ static void getWorldSpaceColliders(world& w)
 		const trs& transform = (c.parent != STATIC_BODY) ? w.bodies[c.parent].transform1 : c.staticTransform;
 		col = c.local;
 		if (c.parent != STATIC_BODY) { col.objectIndex = c.parent; col.objectType = physics_object_type_rigid_body; }
+		else if (c.zoneType != physics_object_type_static_collider) { col.objectIndex = c.zoneIndex; col.objectType = c.zoneType; } // physics.cpp:657-666
 		else { col.objectIndex = dummyRigidBodyIndex; col.objectType = physics_object_type_static_collider; }
 		if (c.parent != STATIC_BODY && w.bodies[c.parent].removed)
 		{
@@ -464,6 +487,9 @@ static void narrowphasePairs(world& w, const collider_pair* inPairs, u32 numPair
 		if (a->objectType == physics_object_type_rigid_body && b->objectType == physics_object_type_rigid_body && a->objectIndex == b->objectIndex) { continue; }
 		pair = (a->type < b->type) ? pair : collider_pair{ pair.colliderB, pair.colliderA }; // NB swaps on equal types (:2374)
 		a = cols + pair.colliderA; b = cols + pair.colliderB;
+		bool collides = (a->objectType == physics_object_type_rigid_body && b->objectType == physics_object_type_rigid_body)
+			|| a->objectType == physics_object_type_static_collider || b->objectType == physics_object_type_static_collider; // :2378-2379
+		if (!collides) { continue; } // force field / trigger vs rigid body: overlap check only (nonCollisionInteractions)
 		++countMatrix[a->type][b->type];
 		kept.push_back(pair);
 	}
@@ -504,6 +530,129 @@ static void narrowphasePairs(world& w, const collider_pair* inPairs, u32 numPair
 			}
 		}
 	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Non-collision interactions (force fields, triggers) and events — collision_narrow.cpp:2573-2593, physics.cpp:759-787, 952-1178.
+// Two deliberate re-statements, shared with the device path: (1) a body inside several localized force fields receives their
+// forces in ascending field id (the reference adds them in the bucket order of its pair list; the sums differ in the last ulp
+// only when three or more terms meet); (2) entity handles are collider / trigger / body ids here, so "sorted by entity pair"
+// means sorted by those ids.
+// ---------------------------------------------------------------------------------------------------
+static vec3 fieldForceWorld(const force_field& f) { return f.hasTransform ? (f.transform.rotation * f.force) : f.force; } // physics.cpp:767-771
+
+static void handleNonCollisionInteractions(world& w)
+{
+	const collider_union* cols = w.worldSpaceColliders.data();
+	u32 numFields = (u32)w.forceFields.size();
+	std::vector<u8> inField((size_t)numFields * w.bodies.size(), 0);
+	std::vector<entity_pair> triggerOverlaps;
+	for (const collider_pair& in : w.broadphasePairs)
+	{
+		collider_pair pair = in;
+		const collider_union* a = cols + pair.colliderA;
+		const collider_union* b = cols + pair.colliderB;
+		bool rbA = a->objectType == physics_object_type_rigid_body, rbB = b->objectType == physics_object_type_rigid_body;
+		if (rbA == rbB) { continue; }                                   // one rigid body ...
+		const collider_union* other = rbA ? b : a;
+		if (other->objectType != physics_object_type_force_field && other->objectType != physics_object_type_trigger) { continue; } // ... and one zone
+		pair = (a->type < b->type) ? pair : collider_pair{ pair.colliderB, pair.colliderA }; // :2374
+		u32 typeKey = cols[pair.colliderA].type * 6 + cols[pair.colliderB].type;
+		w.zoneTested[typeKey]++;
+		if (!overlapColliders(cols[pair.colliderA], cols[pair.colliderB])) { continue; }
+		w.zoneHit[typeKey]++;
+		u32 rigidBodyIndex = (rbA ? a : b)->objectIndex;                 // overlapCheck, :1601-1612
+		if (other->objectType == physics_object_type_force_field) { inField[(size_t)rigidBodyIndex * numFields + other->objectIndex] = 1; }
+		else { triggerOverlaps.push_back(entity_pair{ other->objectIndex, rigidBodyIndex }); }
+	}
+	for (size_t b = 0; b < w.bodies.size(); ++b)
+		for (u32 f = 0; f < numFields; ++f)
+			if (inField[b * numFields + f]) { w.bodies[b].forceAccumulator += fieldForceWorld(w.forceFields[f]); } // physics.cpp:963-967
+
+	std::sort(triggerOverlaps.begin(), triggerOverlaps.end());
+	triggerOverlaps.erase(std::unique(triggerOverlaps.begin(), triggerOverlaps.end()), triggerOverlaps.end()); // several colliders may report the same overlap
+	auto triggerEvent = [&w](entity_pair pair, u32 kind)
+	{
+		event_record e; memset(&e, 0, sizeof(e));
+		e.kind = kind; e.step = w.stepIndex; e.a = pair.a; e.b = pair.b; e.bodyA = STATIC_BODY; e.bodyB = pair.b;
+		w.events.push_back(e);
+	};
+	auto prevIt = w.prevFrameTriggerOverlaps.begin(), prevEnd = w.prevFrameTriggerOverlaps.end();
+	auto thisIt = triggerOverlaps.begin(), thisEnd = triggerOverlaps.end();
+	while (prevIt != prevEnd && thisIt != thisEnd) // physics.cpp:1000-1022
+	{
+		if (*prevIt == *thisIt) { ++prevIt; ++thisIt; continue; }
+		if (*prevIt < *thisIt) { triggerEvent(*prevIt++, event_trigger_leave); }
+		else { triggerEvent(*thisIt++, event_trigger_enter); }
+	}
+	while (prevIt != prevEnd) { triggerEvent(*prevIt++, event_trigger_leave); }
+	while (thisIt != thisEnd) { triggerEvent(*thisIt++, event_trigger_enter); }
+	w.prevFrameTriggerOverlaps = std::move(triggerOverlaps);
+}
+
+static bool globalForceField(const world& w, vec3& sum) // getForceFieldStates, physics.cpp:759-787: fields without a collider act everywhere; EnTT walks newest first
+{
+	bool any = false;
+	sum = vec3(0.f);
+	for (size_t i = w.forceFields.size(); i-- > 0;) { if (!w.forceFields[i].numColliders) { sum += fieldForceWorld(w.forceFields[i]); any = true; } }
+	return any;
+}
+
+static void handleCollisionCallbacks(world& w) // physics.cpp:1037-1178; runs after the force integration: velocities are the pre-solve ones
+{
+	std::vector<collision_entity_pair> collisions;
+	u32 contactOffset = 0;
+	for (size_t i = 0; i < w.collidingPairs.size(); ++i)
+	{
+		u32 numContacts = w.contactCountPerCollision[i];
+		collisions.push_back(collision_entity_pair{ w.collidingPairs[i].colliderA, w.collidingPairs[i].colliderB, contactOffset, numContacts });
+		contactOffset += numContacts;
+	}
+	std::sort(collisions.begin(), collisions.end());
+	if (w.collisionBeginEvents || w.collisionEndEvents)
+	{
+		auto bodyOf = [&w](u32 colliderIndex) { return w.colliders[colliderIndex].parent; };
+		auto beginEvent = [&](const collision_entity_pair& pair)
+		{
+			if (!w.collisionBeginEvents) { return; }
+			const collision_contact* c = w.contacts.data() + pair.contactOffset;
+			float norm = 1.f / pair.numContacts;
+			vec3 point(0.f), normal(0.f);
+			for (u32 i = 0; i < pair.numContacts; ++i) { point += c[i].point; normal += c[i].normal; }
+			point *= norm; normal *= norm;
+			u32 dummy = (u32)w.bodies.size();
+			u32 bodyA = bodyOf(pair.a), bodyB = bodyOf(pair.b);
+			const rigid_body_global_state& rbA = w.rbGlobal[bodyA == STATIC_BODY ? dummy : bodyA];
+			const rigid_body_global_state& rbB = w.rbGlobal[bodyB == STATIC_BODY ? dummy : bodyB];
+			vec3 velA = rbA.linearVelocity + cross(rbA.angularVelocity, point - rbA.position);
+			vec3 velB = rbB.linearVelocity + cross(rbB.angularVelocity, point - rbB.position);
+			vec3 rel = velB - velA;
+			event_record e; memset(&e, 0, sizeof(e));
+			e.kind = event_collision_begin; e.step = w.stepIndex; e.a = pair.a; e.b = pair.b; e.bodyA = bodyA; e.bodyB = bodyB;
+			e.position[0] = point.x; e.position[1] = point.y; e.position[2] = point.z;
+			e.normal[0] = normal.x; e.normal[1] = normal.y; e.normal[2] = normal.z;
+			e.relativeVelocity[0] = rel.x; e.relativeVelocity[1] = rel.y; e.relativeVelocity[2] = rel.z;
+			w.events.push_back(e);
+		};
+		auto endEvent = [&](const collision_entity_pair& pair)
+		{
+			if (!w.collisionEndEvents) { return; }
+			event_record e; memset(&e, 0, sizeof(e));
+			e.kind = event_collision_end; e.step = w.stepIndex; e.a = pair.a; e.b = pair.b; e.bodyA = bodyOf(pair.a); e.bodyB = bodyOf(pair.b);
+			w.events.push_back(e);
+		};
+		auto prevIt = w.prevFrameCollisions.begin(), prevEnd = w.prevFrameCollisions.end();
+		auto thisIt = collisions.begin(), thisEnd = collisions.end();
+		while (prevIt != prevEnd && thisIt != thisEnd)
+		{
+			if (*prevIt == *thisIt) { ++prevIt; ++thisIt; continue; }
+			if (*prevIt < *thisIt) { endEvent(*prevIt++); }
+			else { beginEvent(*thisIt++); }
+		}
+		while (prevIt != prevEnd) { endEvent(*prevIt++); }
+		while (thisIt != thisEnd) { beginEvent(*thisIt++); }
+	}
+	w.prevFrameCollisions = std::move(collisions);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -556,10 +705,20 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 	if (w.usePairOverride) { narrowphaseOverride(w); }
 	else { narrowphasePairs(w, w.broadphasePairs.data(), (u32)w.broadphasePairs.size()); }
 
+	vec3 globalForce;
+	bool anyGlobalForce = globalForceField(w, globalForce);                        // :1253 (a world without global fields skips the += 0 of :1273)
+	if (!w.forceFields.empty() || !w.triggers.empty() || !w.prevFrameTriggerOverlaps.empty()) { handleNonCollisionInteractions(w); } // :1255
+
 	w.rbGlobal.resize(numRigidBodies + 1);
-	for (u32 i = 0; i < numRigidBodies; ++i) { applyGravityAndIntegrateForces(w.bodies[i], w.rbGlobal[i], w.bodies[i].transform1, dt); }
+	for (u32 i = 0; i < numRigidBodies; ++i)
+	{
+		if (anyGlobalForce) { w.bodies[i].forceAccumulator += globalForce; }        // :1273
+		applyGravityAndIntegrateForces(w.bodies[i], w.rbGlobal[i], w.bodies[i].transform1, dt);
+	}
 	memset(&w.rbGlobal[dummyRigidBodyIndex], 0, sizeof(rigid_body_global_state)); // :1279
 	w.rbGlobalPreSolve = w.rbGlobal;
+	handleCollisionCallbacks(w);                                                   // :1284
+	++w.stepIndex;
 	rigid_body_global_state* rbs = w.rbGlobal.data();
 
 	// constraint_solver::initialize (constraints.cpp:3711-3746): joints scalar (joint SIMD variants schedule with
@@ -734,6 +893,56 @@ void orc_use_hull_geometries(world* w) { hullGeometryTable() = &w->hullGeometrie
 
 u32 orc_add_collider(world* w, u32 bodyId, u32 type, const float* shape, const float* material) { return addColliderCommon(w, bodyId, type, shape, material, 0, 0); }
 u32 orc_add_static_collider(world* w, u32 type, const float* shape, const float* material, const float* pos, const float* rot) { return addColliderCommon(w, STATIC_BODY, type, shape, material, pos, rot); }
+
+// ---- force fields, triggers, events ----
+static trs makeTrs(const float* pos, const float* rot)
+{
+	trs t; t.position = pos ? vec3(pos[0], pos[1], pos[2]) : vec3(0.f); t.rotation = rot ? quat(rot[0], rot[1], rot[2], rot[3]) : quat(0.f, 0.f, 0.f, 1.f);
+	return t;
+}
+u32 orc_add_force_field(world* w, const float* force, const float* pos, const float* rot)
+{
+	force_field f; f.force = vec3(force[0], force[1], force[2]); f.hasTransform = (pos || rot); f.transform = makeTrs(pos, rot); f.numColliders = 0;
+	w->forceFields.push_back(f);
+	return (u32)w->forceFields.size() - 1;
+}
+int orc_set_force_field(world* w, u32 field, const float* force) { if (field >= w->forceFields.size()) return 1; w->forceFields[field].force = vec3(force[0], force[1], force[2]); return 0; }
+u32 orc_add_trigger(world* w, const float* pos, const float* rot) { w->triggers.push_back(trigger{ makeTrs(pos, rot), 0 }); return (u32)w->triggers.size() - 1; }
+static u32 addZoneCollider(world* w, u32 zoneType, u32 zoneIndex, const trs& transform, u32 type, const float* shape)
+{
+	const float material[3] = { 0.f, 0.f, 0.f };
+	float pos[3] = { transform.position.x, transform.position.y, transform.position.z }, rot[4] = { transform.rotation.x, transform.rotation.y, transform.rotation.z, transform.rotation.w };
+	u32 id = addColliderCommon(w, STATIC_BODY, type, shape, material, pos, rot);
+	w->colliders[id].zoneType = zoneType; w->colliders[id].zoneIndex = zoneIndex;
+	return id;
+}
+u32 orc_add_force_field_collider(world* w, u32 field, u32 type, const float* shape)
+{
+	if (field >= w->forceFields.size()) return 0xFFFFFFFFu;
+	w->forceFields[field].numColliders++;
+	return addZoneCollider(w, physics_object_type_force_field, field, w->forceFields[field].transform, type, shape);
+}
+u32 orc_add_trigger_collider(world* w, u32 trig, u32 type, const float* shape)
+{
+	if (trig >= w->triggers.size()) return 0xFFFFFFFFu;
+	w->triggers[trig].numColliders++;
+	return addZoneCollider(w, physics_object_type_trigger, trig, w->triggers[trig].transform, type, shape);
+}
+void orc_zone_pair_stats(world* w, u32* outTested36, u32* outHit36) { memcpy(outTested36, w->zoneTested, sizeof(w->zoneTested)); memcpy(outHit36, w->zoneHit, sizeof(w->zoneHit)); }
+// overlapCheck on an ordered pair list (typeA <= typeB per pair), one flag per pair; the boolean twin of orc_narrowphase_ordered
+void orc_overlap_ordered(const void* colliders64, const u32* pairs2, u32 numPairs, u8* outOverlaps)
+{
+	const collider_union* cols = (const collider_union*)colliders64;
+	for (u32 i = 0; i < numPairs; ++i) outOverlaps[i] = overlapColliders(cols[pairs2[2 * i]], cols[pairs2[2 * i + 1]]) ? 1 : 0;
+}
+void orc_enable_collision_events(world* w, int begin, int end) { w->collisionBeginEvents = begin != 0; w->collisionEndEvents = end != 0; }
+u32 orc_drain_events(world* w, void* out60, u32 capacity)
+{
+	u32 n = std::min<u32>((u32)w->events.size(), capacity);
+	if (n) memcpy(out60, w->events.data(), sizeof(event_record) * n);
+	w->events.erase(w->events.begin(), w->events.begin() + n);
+	return n;
+}
 
 static vec3 v3(const float* p) { return vec3(p[0], p[1], p[2]); }
 

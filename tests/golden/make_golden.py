@@ -187,6 +187,28 @@ def gen_kat():
     print("kat: vy", vs[:3], "box", w2.mass_properties()[0, 3:])
 
 
+def overlap_flags(fixture):
+    """Boolean overlapCheck of every broadphase pair of a narrow_pairs fixture (type-ordered like the classify step)."""
+    g = np.load(os.path.join(HERE, fixture), allow_pickle=False)
+    s = scene_from_arrays(g["bodies"], g["colliders"], hull_vertices=g["hull_vertices"], hull_triangles=g["hull_triangles"], hull_ranges=g["hull_ranges"])
+    w = s.instantiate(orc.OracleWorld())
+    w.step_internal(1e-9, 1)
+    w.use_hull_geometries()
+    cols, _ = w.world_colliders()
+    pairs = g["pairs"].astype(np.uint32).copy()
+    swap = ~(cols["type"][pairs[:, 0]] < cols["type"][pairs[:, 1]])   # collision_narrow.cpp:2374 (swaps on equal types too)
+    pairs[swap] = pairs[swap][:, ::-1]
+    return pairs, orc.overlap_ordered(cols, pairs), cols
+
+
+def gen_overlap():
+    out = {}
+    for name in ("narrow_pairs", "narrow_pairs_cylinder", "narrow_pairs_hull"):
+        pairs, flags, _ = overlap_flags(name + ".npz")
+        out[name + "_pairs"] = pairs; out[name + "_overlaps"] = flags
+    np.savez_compressed(os.path.join(HERE, "overlap_pairs.npz"), **out)
+
+
 if __name__ == "__main__":
     orc.build()
     gen_narrow()
@@ -197,3 +219,4 @@ if __name__ == "__main__":
     ragdoll = scenes.c4_ragdolls(1)
     gen_trajectory("ragdoll_trajectory.npz", ragdoll, (1, 30, 120), (("scalar", orc.SOLVER_SCALAR), ("wide8", orc.SOLVER_WIDE8)))
     gen_kat()
+    gen_overlap()

@@ -200,3 +200,101 @@ def test_hull_mass_properties_and_contact(oracle):
     assert len(contacts) == 1
     n = contacts["normal"][0]; d = contacts["depth"][0]
     assert abs(abs(n[1]) - 1.0) < 1e-3 and abs(d - 0.05) < 0.011
+
+
+def test_overlap_checks_golden_and_consistency(oracle, golden_tools):
+    """The boolean overlap tests behind force fields and triggers (overlapCheck, collision_narrow.cpp:1593-1689) on the poses of the three
+    narrowphase fixtures: pinned flags, and agreement with the contact-generating tests of the same pairs.  The two families are separate
+    code in the reference; they must agree except where the reference itself differs: sphereVsCylinder compares a squared distance with
+    the plain radius (bounding_volumes.cpp:723), which only ever adds overlaps for r < 1, and cylinder-cylinder has no parallel closed form."""
+    g = load("overlap_pairs.npz")
+    for name in ("narrow_pairs", "narrow_pairs_cylinder", "narrow_pairs_hull"):
+        pairs, flags, cols = golden_tools.overlap_flags(name + ".npz")
+        assert np.array_equal(pairs, g[name + "_pairs"]) and np.array_equal(flags, g[name + "_overlaps"])
+        colliding = {(int(a), int(b)) for a, b in load(name + ".npz")["colliding_pairs"]}
+        collide = np.array([(int(a), int(b)) in colliding for a, b in pairs])
+        cyl = (cols["type"][pairs[:, 0]] == oracle.CYLINDER) | (cols["type"][pairs[:, 1]] == oracle.CYLINDER)
+        assert np.array_equal(collide[~cyl], flags[~cyl])
+        assert not (collide[cyl] & ~flags[cyl]).any() and (not cyl.any() or (collide[cyl] == flags[cyl]).mean() > 0.9)
+        assert flags.any() and not flags.all()
+
+
+def _one_sphere_world(oracle, pos, gravity_factor=0.0):
+    w = oracle.OracleWorld()
+    b = w.add_body(pos, gravity_factor=gravity_factor, linear_damping=0.0, angular_damping=0.0)
+    w.add_collider(b, oracle.SPHERE, (0, 0, 0, 0.5), (0.1, 0.5, 1.0))
+    return w, b
+
+
+def test_force_field_kat(oracle):
+    """Global field: every body gets F each step (physics.cpp:1273); localized field: only while the body's collider overlaps the field's
+    (:963-967); a field entity's rotation turns the force (:767-771).  v = F / m * dt with m = 4/3 pi r^3 (density 1), no damping."""
+    dt = np.float32(1.0 / 120.0)
+    inv_mass = np.float32(1.0) / np.float32(4.0 / 3.0 * np.pi * 0.125)
+    w, b = _one_sphere_world(oracle, (0, 10, 0))
+    w.add_force_field((2.0, 0.0, 0.0))
+    w.add_force_field((0.0, 0.0, 1.0), rot=(0.0, 0.70710678, 0.0, 0.70710678))   # +z turned by 90 deg about y -> +x
+    w.step_internal(float(dt), 1)
+    v = w.velocities()[0, :3]
+    np.testing.assert_allclose(v, [3.0 * inv_mass * dt, 0.0, 0.0], rtol=1e-6, atol=1e-7)
+
+    w, b = _one_sphere_world(oracle, (0, 10, 0))
+    f = w.add_force_field((0.0, 5.0, 0.0), pos=(0.0, 10.0, 0.0))
+    w.add_force_field_collider(f, oracle.AABB, (-1, -1, -1, 1, 1, 1))
+    far = w.add_body((20, 10, 0), gravity_factor=0.0, linear_damping=0.0, angular_damping=0.0)
+    w.add_collider(far, oracle.SPHERE, (0, 0, 0, 0.5), (0.1, 0.5, 1.0))
+    w.step_internal(float(dt), 1)
+    v = w.velocities()
+    np.testing.assert_allclose(v[0, :3], [0.0, 5.0 * inv_mass * dt, 0.0], rtol=1e-6)
+    assert not v[1].any()
+    w.set_force_field(f, (0.0, 0.0, 0.0))
+    w.step_internal(float(dt), 1)
+    np.testing.assert_allclose(w.velocities()[0, :3], [0.0, 5.0 * inv_mass * dt, 0.0], rtol=1e-6)
+
+
+def test_trigger_and_collision_events_kat(oracle):
+    """A sphere dropped through a trigger box onto the ground: enter, leave, then a collision begin whose record carries the contact point
+    under the sphere, the normal along y and the approach velocity; lifted away afterwards: collision end.  Events come out per step in the
+    reference's callback order (physics.cpp:1000-1032, 1128-1174)."""
+    w, b = _one_sphere_world(oracle, (0, 4, 0), gravity_factor=1.0)
+    ground = w.add_static_collider(oracle.AABB, (-10, -1, -10, 10, 0, 10), (0.1, 0.5, 1.0))
+    t = w.add_trigger(pos=(0, 2, 0))
+    w.add_trigger_collider(t, oracle.AABB, (-1, -0.25, -1, 1, 0.25, 1))
+    w.add_trigger_collider(t, oracle.SPHERE, (0, 0, 0, 0.3))          # overlaps the box: still one event per body
+    w.enable_collision_events()
+    events = []
+    for _ in range(150):
+        w.step_internal(1.0 / 120.0, 30)
+        events.extend(w.drain_events())
+    kinds = [int(e["kind"]) for e in events]
+    assert kinds[:3] == [oracle.TRIGGER_ENTER, oracle.TRIGGER_LEAVE, oracle.COLLISION_BEGIN], kinds
+    enter, leave, begin = events[:3]
+    assert enter["a"] == t and enter["b"] == b and leave["a"] == t and leave["b"] == b and enter["step"] < leave["step"] < begin["step"]
+    assert begin["bodyA"] == b and begin["bodyB"] == oracle.STATIC and begin["b"] == ground
+    assert abs(begin["position"][1]) < 0.05 and abs(abs(begin["normal"][1]) - 1.0) < 1e-6
+    assert begin["relativeVelocity"][1] > 3.0      # B (static) minus A (falling sphere)
+    w.set_velocity(b, (0, 6.0, 0), (0, 0, 0))
+    tail = []
+    for _ in range(220):
+        w.step_internal(1.0 / 120.0, 30)
+        tail.extend(w.drain_events())
+    assert int(tail[0]["kind"]) == oracle.COLLISION_END
+    assert [int(e["kind"]) for e in tail if e["kind"] < 2][:2] == [oracle.TRIGGER_ENTER, oracle.TRIGGER_LEAVE]
+
+
+def test_zones_scene_reaches_every_overlap_pair(oracle):
+    """The `zones` parity scene exercises all 21 boolean type pairs, hits and misses, and raises all four event kinds."""
+    from directx_renderer_kurth_amd import scenes
+    s = scenes.by_name("zones")
+    w = s.instantiate(oracle.OracleWorld())
+    kinds = set()
+    for _ in range(150):
+        w.step_internal(s.dt, 8)
+        kinds.update(int(k) for k in w.drain_events()["kind"])
+    tested, hit = w.zone_pair_stats()
+    iu = np.triu_indices(6)
+    assert (tested[iu] > 0).all(), tested
+    miss = tested - hit
+    miss[3, 3] = 1  # two world-space AABBs that pass the broadphase overlap by definition
+    assert (hit[iu] > 0).all() and (miss[iu] > 0).all(), (tested, hit)
+    assert kinds == {0, 1, 2, 3}
