@@ -3,6 +3,7 @@
 // physicsStep() and prints the final poses (tests/test_gpu_facade.py compares them with the same world built through the ctypes mirror).
 // Build: g++ -std=c++17 -Iinclude example_facade.cpp -L.. -lmi_physics
 #include <cstdio>
+#include <cstdlib>
 #include "physics_facade.hpp"
 
 using namespace mi;
@@ -40,10 +41,25 @@ int main()
 			h->motorType = constraint_velocity_motor; h->motorVelocity = 0.5f; h->maxMotorTorque = 50.f;
 		}
 
+		// a global wind, an updraft box over the pile, and a trigger slab the boxes fall through (physics.h:182-203)
+		scene.createEntity("wind").addComponent<force_field_component>(vec3(0.5f, 0.f, 0.f));
+		scene.createEntity("updraft")
+			.addComponent<transform_component>(vec3(0.f, 6.f, 0.f), quat())
+			.addComponent<collider_component>(collider_component::asAABB(bounding_box::fromCenterRadius(vec3(0.f, 0.f, 0.f), vec3(2.f, 1.f, 2.f)), mat))
+			.addComponent<force_field_component>(vec3(0.f, 8.f, 0.f));
+		int enters = 0, leaves = 0, begins = 0, ends = 0;
+		auto slab = scene.createEntity("slab");
+		slab.addComponent<transform_component>(vec3(0.f, 3.f, 0.f), quat())
+			.addComponent<trigger_component>([&](trigger_event e) { (e.type == trigger_event_enter ? enters : leaves)++; if (!(e.trigger == slab)) std::abort(); })
+			.addComponent<collider_component>(collider_component::asAABB(bounding_box::fromCenterRadius(vec3(0.f, 0.f, 0.f), vec3(3.f, 0.25f, 3.f)), mat));
+
 		memory_arena arena; physics_settings settings; float timer = 0.f;
+		settings.collisionBeginCallback = [&](const collision_begin_event& e) { ++begins; if (e.colliderA.type > e.colliderB.type) std::abort(); };
+		settings.collisionEndCallback = [&](const collision_end_event&) { ++ends; };
 		for (int frame = 0; frame < 120; ++frame) physicsStep(scene, arena, timer, settings, 1.f / 60.f);
 
 		for (auto& e : boxes) { auto t = e.transform(); std::printf("box %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", t.position.x, t.position.y, t.position.z, t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w); }
+		std::printf("events %d %d %d %d\n", enters, leaves, begins, ends);
 		auto t = bob.transform(); std::printf("bob %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", t.position.x, t.position.y, t.position.z, t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w);
 		return 0;
 	}

@@ -20,10 +20,12 @@
 
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "mi_physics.h"
@@ -68,9 +70,23 @@ namespace mi
 		rigid_body_component(bool k = false, float g = 1.f, float l = 0.4f, float a = 0.4f) : kinematic(k), gravityFactor(g), linearDamping(l), angularDamping(a) {}
 	};
 
-	// physics_settings, physics.h:382-397 (callbacks: out of scope)
+	struct scene_entity;
+	// force_field_component (physics.h:182-185): on an entity without colliders the force acts on every rigid body, with colliders on
+	// the bodies overlapping them; the entity's transform_component (if it has one) rotates the force
+	struct force_field_component { vec3 force; force_field_component(vec3 f = {}) : force(f) {} };
+	// trigger_event / trigger_component (physics.h:187-203)
+	enum trigger_event_type { trigger_event_enter, trigger_event_leave };
+	struct trigger_event;
+	struct trigger_component { std::function<void(trigger_event)> callback; trigger_component(std::function<void(trigger_event)> cb = {}) : callback(std::move(cb)) {} };
+	struct collision_begin_event;
+	struct collision_end_event;
+	typedef std::function<void(const collision_begin_event&)> collision_begin_event_func; // physics.h:379-380
+	typedef std::function<void(const collision_end_event&)> collision_end_event_func;
+
+	// physics_settings, physics.h:382-397
 	struct physics_settings
 	{
+		collision_begin_event_func collisionBeginCallback; collision_end_event_func collisionEndCallback;
 		bool fixedFrameRate = true; uint32_t frameRate = 120; uint32_t maxPhysicsIterationsPerFrame = 4; uint32_t numRigidSolverIterations = 30;
 		uint32_t numClothVelocityIterations = 0, numClothPositionIterations = 1, numClothDriftIterations = 0;
 		bool simdBroadPhase = true, simdNarrowPhase = true, simdConstraintSolver = true;
@@ -134,11 +150,19 @@ namespace mi
 		uint32_t body() const;
 		transform_component transform() const; // transform_component after the last physicsStep (interpolated)
 		vec3 linearVelocity() const;
+		bool operator==(const scene_entity& o) const { return scene == o.scene && index == o.index; }
 	};
+	struct trigger_event { scene_entity trigger, other; trigger_event_type type; };                                       // physics.h:193-198
+	struct collision_begin_event { scene_entity entityA, entityB; const collider_component& colliderA; const collider_component& colliderB; vec3 position, normal, relativeVelocity; }; // physics.h:356-367
+	struct collision_end_event { scene_entity entityA, entityB; const collider_component& colliderA; const collider_component& colliderB; };                                          // physics.h:369-376
 
 	struct game_scene
 	{
-		struct entity_record { transform_component transform; uint32_t body = MI_STATIC_BODY; std::vector<collider_component> pending; std::vector<uint32_t> colliders; };
+		struct entity_record
+		{
+			transform_component transform; bool hasTransform = false; uint32_t body = MI_STATIC_BODY, field = 0xFFFFFFFFu, trigger = 0xFFFFFFFFu;
+			std::vector<collider_component> pending; std::vector<uint32_t> colliders; trigger_component triggerComponent;
+		};
 
 		explicit game_scene(int device = -1)
 		{
@@ -166,46 +190,111 @@ namespace mi
 
 		void flushStaticColliders()
 		{
-			for (auto& e : entities)
+			for (uint32_t i = 0; i < (uint32_t)entities.size(); ++i)
 			{
+				auto& e = entities[i];
 				if (e.body != MI_STATIC_BODY) continue;
 				for (auto& c : e.pending)
 				{
 					mi_material m{ c.material.restitution, c.material.friction, c.material.density };
-					e.colliders.push_back(checkId(mi_add_static_collider(world, c.type, c.shape, &m, &e.transform.position.x, &e.transform.rotation.x), "mi_add_static_collider"));
+					uint32_t id = checkId(mi_add_static_collider(world, c.type, c.shape, &m, &e.transform.position.x, &e.transform.rotation.x), "mi_add_static_collider");
+					registerCollider(i, id, c);
 				}
 				e.pending.clear();
+			}
+		}
+		// collider id -> owning entity + component (the events name colliders by id); body / trigger id -> entity
+		void registerCollider(uint32_t entityIndex, uint32_t id, const collider_component& c)
+		{
+			entities[entityIndex].colliders.push_back(id);
+			if (colliderEntity.size() <= id) { colliderEntity.resize(id + 1, 0xFFFFFFFFu); colliderComponents.resize(id + 1); }
+			colliderEntity[id] = entityIndex; colliderComponents[id] = c;
+		}
+		void addZoneCollider(uint32_t entityIndex, const collider_component& c) // collider of a force-field / trigger entity (physics.cpp:657-666)
+		{
+			auto& e = entities[entityIndex];
+			uint32_t id = (e.field != 0xFFFFFFFFu) ? mi_add_force_field_collider(world, e.field, c.type, c.shape) : mi_add_trigger_collider(world, e.trigger, c.type, c.shape);
+			registerCollider(entityIndex, checkId(id, "zone collider"), c);
+		}
+		// drains the device's events and calls back in the reference's order (physics.cpp:1000-1032, 1128-1174)
+		void dispatchEvents(const physics_settings& settings)
+		{
+			mi_event buffer[256];
+			for (;;)
+			{
+				uint32_t n = mi_drain_events(world, buffer, 256);
+				for (uint32_t i = 0; i < n; ++i)
+				{
+					const mi_event& e = buffer[i];
+					if (e.kind == MI_EVENT_TRIGGER_ENTER || e.kind == MI_EVENT_TRIGGER_LEAVE)
+					{
+						uint32_t t = triggerEntity[e.a];
+						if (entities[t].triggerComponent.callback)
+							entities[t].triggerComponent.callback(trigger_event{ scene_entity{ this, t }, scene_entity{ this, bodyEntity[e.b] }, e.kind == MI_EVENT_TRIGGER_ENTER ? trigger_event_enter : trigger_event_leave });
+						continue;
+					}
+					scene_entity a{ this, colliderEntity[e.a] }, b{ this, colliderEntity[e.b] };
+					if (e.kind == MI_EVENT_COLLISION_BEGIN && settings.collisionBeginCallback)
+						settings.collisionBeginCallback(collision_begin_event{ a, b, colliderComponents[e.a], colliderComponents[e.b],
+							vec3(e.position[0], e.position[1], e.position[2]), vec3(e.normal[0], e.normal[1], e.normal[2]), vec3(e.relativeVelocity[0], e.relativeVelocity[1], e.relativeVelocity[2]) });
+					else if (e.kind == MI_EVENT_COLLISION_END && settings.collisionEndCallback)
+						settings.collisionEndCallback(collision_end_event{ a, b, colliderComponents[e.a], colliderComponents[e.b] });
+				}
+				if (n < 256) break;
 			}
 		}
 
 		mi_world* world = nullptr;
 		std::vector<entity_record> entities;
+		std::vector<uint32_t> colliderEntity, bodyEntity, triggerEntity; std::vector<collider_component> colliderComponents;
+		int collisionEventMask = -1;
 	};
 
 	template <typename T, typename... Args> inline scene_entity& scene_entity::addComponent(Args&&... args)
 	{
 		auto& e = scene->entities[index];
-		if constexpr (std::is_same_v<T, transform_component>) { e.transform = transform_component(std::forward<Args>(args)...); }
+		if constexpr (std::is_same_v<T, transform_component>) { e.transform = transform_component(std::forward<Args>(args)...); e.hasTransform = true; }
 		else if constexpr (std::is_same_v<T, collider_component>)
 		{
 			collider_component c(std::forward<Args>(args)...);
-			if (e.body == MI_STATIC_BODY) e.pending.push_back(c);
+			if (e.field != 0xFFFFFFFFu || e.trigger != 0xFFFFFFFFu) scene->addZoneCollider(index, c);
+			else if (e.body == MI_STATIC_BODY) e.pending.push_back(c);
 			else
 			{
 				mi_material m{ c.material.restitution, c.material.friction, c.material.density };
-				e.colliders.push_back(scene->checkId(mi_add_collider(scene->world, e.body, c.type, c.shape, &m), "mi_add_collider"));
+				scene->registerCollider(index, scene->checkId(mi_add_collider(scene->world, e.body, c.type, c.shape, &m), "mi_add_collider"), c);
 			}
+		}
+		else if constexpr (std::is_same_v<T, force_field_component> || std::is_same_v<T, trigger_component>)
+		{
+			const float* pos = e.hasTransform ? &e.transform.position.x : nullptr; const float* rot = e.hasTransform ? &e.transform.rotation.x : nullptr;
+			if constexpr (std::is_same_v<T, force_field_component>)
+			{
+				force_field_component f(std::forward<Args>(args)...);
+				e.field = scene->checkId(mi_add_force_field(scene->world, &f.force.x, pos, rot), "mi_add_force_field");
+			}
+			else
+			{
+				e.triggerComponent = trigger_component(std::forward<Args>(args)...);
+				e.trigger = scene->checkId(mi_add_trigger(scene->world, pos, rot), "mi_add_trigger");
+				if (scene->triggerEntity.size() <= e.trigger) scene->triggerEntity.resize(e.trigger + 1, 0xFFFFFFFFu);
+				scene->triggerEntity[e.trigger] = index;
+			}
+			std::vector<collider_component> pending; pending.swap(e.pending);
+			for (auto& c : pending) scene->addZoneCollider(index, c);
 		}
 		else if constexpr (std::is_same_v<T, rigid_body_component>)
 		{
 			rigid_body_component rb(std::forward<Args>(args)...);
 			e.body = scene->checkId(mi_add_body(scene->world, rb.kinematic, rb.gravityFactor, rb.linearDamping, rb.angularDamping, &e.transform.position.x, &e.transform.rotation.x), "mi_add_body");
-			for (auto& c : e.pending)
+			if (scene->bodyEntity.size() <= e.body) scene->bodyEntity.resize(e.body + 1, 0xFFFFFFFFu);
+			scene->bodyEntity[e.body] = index;
+			std::vector<collider_component> pending; pending.swap(e.pending);
+			for (auto& c : pending)
 			{
 				mi_material m{ c.material.restitution, c.material.friction, c.material.density };
-				e.colliders.push_back(scene->checkId(mi_add_collider(scene->world, e.body, c.type, c.shape, &m), "mi_add_collider"));
+				scene->registerCollider(index, scene->checkId(mi_add_collider(scene->world, e.body, c.type, c.shape, &m), "mi_add_collider"), c);
 			}
-			e.pending.clear();
 		}
 		else static_assert(sizeof(T) == 0, "component type not on the rigid-body path");
 		return *this;
@@ -281,6 +370,9 @@ namespace mi
 		s.numRigidSolverIterations = settings.numRigidSolverIterations;
 		s.numClothVelocityIterations = settings.numClothVelocityIterations; s.numClothPositionIterations = settings.numClothPositionIterations; s.numClothDriftIterations = settings.numClothDriftIterations;
 		s.simdBroadPhase = settings.simdBroadPhase; s.simdNarrowPhase = settings.simdNarrowPhase; s.simdConstraintSolver = settings.simdConstraintSolver;
+		int mask = (settings.collisionBeginCallback ? 1 : 0) | (settings.collisionEndCallback ? 2 : 0);
+		if (mask != scene.collisionEventMask) { scene.check(mi_enable_collision_events(scene.world, mask & 1, mask & 2), "mi_enable_collision_events"); scene.collisionEventMask = mask; }
 		scene.check(mi_step(scene.world, &timer, &s, dt), "physicsStep");
+		scene.dispatchEvents(settings);
 	}
 }

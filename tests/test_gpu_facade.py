@@ -29,7 +29,9 @@ def test_facade_compiles_and_links(tmp_path):
 def test_facade_matches_ctypes_world(tmp_path, mi):
     exe = build_example(tmp_path)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    got = np.array([[float(x) for x in line.split()[1:]] for line in out.strip().splitlines()], np.float32)
+    lines = out.strip().splitlines()
+    got = np.array([[float(x) for x in line.split()[1:]] for line in lines if not line.startswith("events")], np.float32)
+    got_events = [int(x) for x in [line for line in lines if line.startswith("events")][0].split()[1:]]
 
     w = mi.World()
     mat = (0.1, 0.5, 1.0)
@@ -49,8 +51,16 @@ def test_facade_matches_ctypes_world(tmp_path, mi):
     pod[60:64].view(np.uint32)[0] = 0              # constraint_velocity_motor
     pod[64:68].view(np.float32)[0] = 0.5
     w.constraint_set(mi.HINGE, h, pod)
+    w.add_force_field((0.5, 0, 0))
+    f = w.add_force_field((0, 8.0, 0), pos=(0, 6, 0), rot=(0, 0, 0, 1))
+    w.add_force_field_collider(f, mi.AABB, [-2, -1, -2, 2, 1, 2])
+    trig = w.add_trigger(pos=(0, 3, 0), rot=(0, 0, 0, 1))
+    w.add_trigger_collider(trig, mi.AABB, [-3, -0.25, -3, 3, 0.25, 3])
+    w.enable_collision_events()
     for _ in range(120):
         w.step(1.0 / 60.0, mi.Settings())
+    ev = w.drain_events()
+    assert got_events == np.bincount(ev["kind"], minlength=4).tolist() and got_events[0] >= 2 and got_events[2] >= 8
     t = w.transforms(0)[ids + [bob]]
     # printed with 6 decimals
     np.testing.assert_allclose(got, t, atol=2e-6)
