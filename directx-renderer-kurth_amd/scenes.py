@@ -56,6 +56,7 @@ class Scene:
         self.fields = []      # force fields: (force3, pos3 or None, rot4 or None, [(type, shape), ...]); no colliders = global
         self.triggers = []    # triggers: (pos3 or None, rot4 or None, [(type, shape), ...])
         self.collision_events = False
+        self.joint_edits = []  # (kind, index within kind, [(byte offset, "f4"|"u4", value), ...]): getConstraint(...).field = value after creation
 
     def add_body(self, pos, rot=(0, 0, 0, 1), kinematic=False, gravity_factor=1.0, linear_damping=0.4, angular_damping=0.4):
         self.bodies.append((tuple(float(x) for x in pos), tuple(float(x) for x in rot), kinematic, gravity_factor, linear_damping, angular_damping))
@@ -97,6 +98,13 @@ class Scene:
         for j in self.joints:
             kind, a, b, args = j[0], j[1], j[2], j[3:]
             getattr(world, "add_%s_constraint_global" % kind)(a, b, *args)
+        kinds = {"distance": (0, 28), "ball": (1, 24), "fixed": (2, 40), "hinge": (3, 104), "cone_twist": (4, 120), "slider": (5, 72)}
+        for kind, index, edits in self.joint_edits:
+            ctype, nbytes = kinds[kind]
+            pod = world.constraint_get(ctype, index, nbytes)
+            for offset, dtype, value in edits:
+                pod[offset:offset + 4].view(np.float32 if dtype == "f4" else np.uint32)[0] = value
+            world.constraint_set(ctype, index, pod)
         for force, pos, rot, cols in self.fields:
             f = world.add_force_field(force, pos, rot)
             for ctype, shape in cols:
@@ -316,6 +324,205 @@ def _qrot(q, v):
     return (r[0], r[1], r[2])
 
 
+def _rotate_from_to(frm, to):
+    """rotateFromTo (core/math.cpp): shortest rotation taking `frm` to `to`."""
+    f = np.asarray(frm, np.float64); f = f / np.linalg.norm(f)
+    t = np.asarray(to, np.float64); t = t / np.linalg.norm(t)
+    d = float(f @ t)
+    if d >= 1.0:
+        return (0.0, 0.0, 0.0, 1.0)
+    if d < 1e-6 - 1.0:
+        axis = np.cross((1.0, 0.0, 0.0), f)
+        if not axis.any():
+            axis = np.cross((0.0, 1.0, 0.0), f)
+        axis = axis / np.linalg.norm(axis)
+        return _quat_axis_angle(tuple(axis), math.pi)
+    sq = math.sqrt((1.0 + d) * 2.0)
+    c = np.cross(f, t) / sq
+    q = np.array([c[0], c[1], c[2], sq * 0.5]); q = q / np.linalg.norm(q)
+    return tuple(float(x) for x in q)
+
+
+# hinge_constraint field offsets (constraints.h:229-257)
+HINGE_MAX_MOTOR_TORQUE, HINGE_MOTOR_TYPE, HINGE_MOTOR_VELOCITY = 56, 60, 64
+VELOCITY_MOTOR, POSITION_MOTOR = 0, 1
+
+VEHICLE_PARTS = ["motor", "motorGear", "driveAxis", "frontAxis", "steeringWheel", "steeringAxis", "leftWheelSuspension", "rightWheelSuspension",
+                 "leftFrontWheel", "rightFrontWheel", "leftWheelArm", "rightWheelArm", "differentialSunGear", "differentialSpiderGear",
+                 "leftRearWheel", "rightRearWheel"]
+
+
+def add_vehicle(s, position=(0.0, 1.5, 0.0), yaw=0.0, motor_velocity=0.0):
+    """vehicle::initialize (vehicle.cpp:283-485): 16 bodies — a motor block, gears whose colliders are their capsule teeth (the gear disks
+    are render-only), a rack-and-pinion steering, a differential, four cylinder wheels — held together by 11 hinges (the motor one driven,
+    the steering wheel position-controlled), 1 fixed, 1 slider and 4 ball joints.  Rods and wheel suspensions carry no colliders (they
+    penetrate the wheels).  Everything is laid out around the origin, joints are made from global points there, then every part is moved
+    by (yaw about y, position) like the reference does at the end.  Returns {part name: body id} and {"motor" / "steering": hinge index}."""
+    Y, X, Z = (0.0, 1.0, 0.0), (1.0, 0.0, 0.0), (0.0, 0.0, 1.0)
+    ident = (0.0, 0.0, 0.0, 1.0)
+    d2r = math.pi / 180.0
+    density = 2000.0
+    place_q = _quat_axis_angle(Y, yaw)
+
+    def add(a, b):
+        return tuple(x + y for x, y in zip(a, b))
+
+    def sub(a, b):
+        return tuple(x - y for x, y in zip(a, b))
+
+    def placed_point(pt):
+        return add(_qrot(place_q, pt), position)
+
+    bodies = {}
+    hinge_base = sum(1 for j in s.joints if j[0] == "hinge")
+    hinges = []
+
+    def make_body(name, pos, rot):
+        bodies[name] = s.add_body(placed_point(pos), _qmul(place_q, rot))
+        return bodies[name]
+
+    def joint(kind, a, b, anchor, *rest):
+        args = [placed_point(anchor)]
+        if kind in ("hinge", "slider"):
+            args.append(_qrot(place_q, rest[0]))
+            args.extend(rest[1:])
+        s.add_joint(kind, bodies[a], bodies[b], *args)
+        if kind == "hinge":
+            hinges.append((a, b))
+            return hinge_base + len(hinges) - 1
+        return None
+
+    def gear(height, radius, teeth, tooth_length, tooth_width, friction, dens):
+        return ("gear", height, radius, teeth, tooth_length, tooth_width, friction, dens)
+
+    def attach(body, attachment, rod_length, sign):
+        rod_offset = rod_length * sign
+        if attachment[0] == "gear":
+            _, height, radius, teeth, tlen, twid, friction, dens = attachment
+            for i in range(teeth):
+                lr = _quat_axis_angle(Y, i * 2.0 * math.pi / teeth)
+                center = add(_qrot(lr, (radius + tlen * 0.5, 0.0, 0.0)), (0.0, rod_offset, 0.0))
+                half = _qrot(lr, (tlen * 0.5, 0.0, 0.0))
+                s.add_collider(body, CAPSULE, sub(center, half) + add(center, half) + (twid * 0.5,), (0.2, friction, dens))
+        elif attachment[0] == "wheel":
+            _, height, radius, friction, dens = attachment
+            s.add_collider(body, CYLINDER, (0.0, rod_offset - height * 0.5, 0.0, 0.0, rod_offset + height * 0.5, 0.0, radius), (0.2, friction, dens))
+
+    def create_axis(name, pos, rot, desc, first=None, second=None):   # createAxis, vehicle.cpp:147-175
+        b = make_body(name, pos, rot)
+        attach(b, desc, 0.0, 1.0)
+        if first:
+            attach(b, first[0], first[1], 1.0)
+        if second:
+            attach(b, second[0], second[1], -1.0)
+        return b
+
+    def create_rod(name, frm, to):                                     # createRod, vehicle.cpp:257-281: no collider
+        axis = sub(to, frm)
+        return make_body(name, tuple((a + b) * 0.5 for a, b in zip(frm, to)), _rotate_from_to(Y, axis))
+
+    motor_gear = gear(0.1, 0.2, 8, 0.07, 0.1, 0.0, density)
+    steering_wheel_desc = gear(0.1, 0.4, 0, 0.07, 0.1, 0.0, density)
+    wheel = ("wheel", 0.3, 0.7, 1.0, 50.0)
+    motor_gear_y, gear_offset = 0.25, 0.26
+
+    m = make_body("motor", (0.0, 0.0, 0.0), ident)
+    s.add_collider(m, AABB, (-0.6, -0.1, -1.0, 0.6, 0.1, 1.0), (0.2, 0.0, density))
+
+    create_axis("motorGear", (0.0, motor_gear_y, 0.0), ident, motor_gear)
+    motor_hinge = joint("hinge", "motor", "motorGear", (0.0, motor_gear_y, 0.0), Y, 1.0, -1.0)
+
+    drive_axis_length = 4.5
+    create_axis("driveAxis", (0.0, motor_gear_y + gear_offset, gear_offset), _quat_axis_angle((-1.0, 0.0, 0.0), 90 * d2r), motor_gear,
+                None, (motor_gear, drive_axis_length * 0.57 - 1.1))
+    joint("hinge", "motor", "driveAxis", (0.0, motor_gear_y + gear_offset, gear_offset), Z, 1.0, -1.0)
+
+    axis_length, suspension_length = 1.5, 0.4
+    front_axis_offset_z = -drive_axis_length * 0.5 + gear_offset * 2.0
+    front_axis_pos = (0.0, motor_gear_y + gear_offset, front_axis_offset_z)
+    create_rod("frontAxis", add(front_axis_pos, (axis_length, 0.0, 0.0)), sub(front_axis_pos, (axis_length, 0.0, 0.0)))
+    joint("fixed", "motor", "frontAxis", front_axis_pos)
+
+    steering_wheel_rot = _quat_axis_angle((-1.0, 0.0, 0.0), -80 * d2r)
+    steering_wheel_pos = (0.0, 1.12, 0.81)
+    create_axis("steeringWheel", steering_wheel_pos, steering_wheel_rot, steering_wheel_desc, None, (motor_gear, 2.0))
+    steering_hinge = joint("hinge", "motor", "steeringWheel", steering_wheel_pos, _qrot(steering_wheel_rot, (0.0, -1.0, 0.0)), 1.0, -1.0)
+
+    steering_axis_pos = (0.0, motor_gear_y + gear_offset + 0.06, front_axis_offset_z + 0.49)
+    steering_axis_length = axis_length * 1.05
+    sa = make_body("steeringAxis", steering_axis_pos, steering_wheel_rot)   # createGearAxis, vehicle.cpp:177-222: a rack of 8 capsule teeth
+    tooth_length, tooth_width = 0.07, 0.1
+    stride = (steering_axis_length - tooth_width) / 7.0
+    for i in range(8):
+        x = -0.5 * steering_axis_length + 0.5 * tooth_width + i * stride
+        s.add_collider(sa, CAPSULE, (x, tooth_width * 0.5 + tooth_length * 0.5, 0.0, x, tooth_width * 0.5 - tooth_length * 0.5, 0.0, tooth_width * 0.5), (0.2, 0.0, density))
+    joint("slider", "motor", "steeringAxis", steering_axis_pos, X, -4.0, 4.0)
+    left_rack_end = sub(steering_axis_pos, (steering_axis_length * 0.5, 0.0, 0.0))
+    right_rack_end = add(steering_axis_pos, (steering_axis_length * 0.5, 0.0, 0.0))
+
+    left_susp_pos = sub(front_axis_pos, (axis_length, 0.0, 0.0))
+    left_susp_attach = add(left_susp_pos, (0.0, 0.0, suspension_length))
+    make_body("leftWheelSuspension", left_susp_pos, ident)              # createWheelSuspension: no collider
+    joint("hinge", "motor", "leftWheelSuspension", left_susp_pos, Y, -45 * d2r, 45 * d2r)
+    right_susp_pos = add(front_axis_pos, (axis_length, 0.0, 0.0))
+    right_susp_attach = add(right_susp_pos, (0.0, 0.0, suspension_length))
+    make_body("rightWheelSuspension", right_susp_pos, ident)
+    joint("hinge", "motor", "rightWheelSuspension", right_susp_pos, Y, -45 * d2r, 45 * d2r)
+
+    wheel_rot = _quat_axis_angle(Z, 90 * d2r)
+    left_front_pos = sub(left_susp_pos, (suspension_length * 0.5, 0.0, 0.0))
+    lf = make_body("leftFrontWheel", left_front_pos, wheel_rot)          # createWheel, vehicle.cpp:224-247
+    attach(lf, wheel, 0.0, 1.0)
+    right_front_pos = add(right_susp_pos, (suspension_length * 0.5, 0.0, 0.0))
+    rf = make_body("rightFrontWheel", right_front_pos, wheel_rot)
+    attach(rf, wheel, 0.0, 1.0)
+    joint("hinge", "leftFrontWheel", "leftWheelSuspension", left_front_pos, X, 1.0, -1.0)
+    joint("hinge", "rightFrontWheel", "rightWheelSuspension", right_front_pos, X, 1.0, -1.0)
+
+    create_rod("leftWheelArm", left_rack_end, left_susp_attach)
+    create_rod("rightWheelArm", right_rack_end, right_susp_attach)
+    joint("ball", "leftWheelSuspension", "leftWheelArm", left_susp_attach)
+    joint("ball", "steeringAxis", "leftWheelArm", left_rack_end)
+    joint("ball", "rightWheelSuspension", "rightWheelArm", right_susp_attach)
+    joint("ball", "steeringAxis", "rightWheelArm", right_rack_end)
+
+    rear_gear = gear(0.1, 0.5, 17, 0.07, 0.1, 0.0, density)
+    rear_z, rear_x = drive_axis_length * 0.505, -gear_offset
+    sun_pos = (rear_x, motor_gear_y + gear_offset, rear_z)
+    create_axis("differentialSunGear", sun_pos, _quat_axis_angle((0.0, 0.0, -1.0), 90 * d2r), rear_gear)
+    joint("hinge", "motor", "differentialSunGear", sun_pos, X, 1.0, -1.0)
+
+    spider_pos = (0.11, motor_gear_y + gear_offset * 2.0, rear_z)
+    create_axis("differentialSpiderGear", spider_pos, ident, motor_gear, (("none",), 0.2))
+    joint("hinge", "differentialSunGear", "differentialSpiderGear", spider_pos, Y, 1.0, -1.0)
+
+    left_rear_pos = add(spider_pos, (-gear_offset, -gear_offset, 0.0))
+    right_rear_pos = add(spider_pos, (gear_offset, -gear_offset, 0.0))
+    rear_rot = _quat_axis_angle((0.0, 0.0, -1.0), 90 * d2r)
+    create_axis("leftRearWheel", left_rear_pos, rear_rot, motor_gear, None, (wheel, axis_length + spider_pos[0]))
+    create_axis("rightRearWheel", right_rear_pos, rear_rot, motor_gear, (wheel, axis_length - spider_pos[0]), None)
+    joint("hinge", "motor", "leftRearWheel", left_rear_pos, X, 1.0, -1.0)
+    joint("hinge", "motor", "rightRearWheel", right_rear_pos, X, 1.0, -1.0)
+
+    # getConstraint(scene, handle).field = ... (vehicle.cpp:371-373, 399-402)
+    s.joint_edits.append(("hinge", motor_hinge, [(HINGE_MAX_MOTOR_TORQUE, "f4", 500.0), (HINGE_MOTOR_VELOCITY, "f4", motor_velocity)]))
+    s.joint_edits.append(("hinge", steering_hinge, [(HINGE_MOTOR_TYPE, "u4", POSITION_MOTOR), (HINGE_MAX_MOTOR_TORQUE, "f4", 1000.0), (HINGE_MOTOR_VELOCITY, "f4", 0.0)]))
+    return bodies, {"motor": motor_hinge, "steering": steering_hinge}
+
+
+def vehicles(n=1, motor_velocity=3.0, pitch=8.0):
+    """n gear-driven vehicles (vehicle.cpp) on the ground, motors running: compound capsule-tooth gears meshing through contacts, cylinder
+    wheels on an AABB floor, every joint type but distance and cone-twist."""
+    s = Scene("vehicles_%d" % n, dt=1.0 / 120.0)
+    side = int(math.ceil(math.sqrt(n)))
+    _ground(s, side * pitch * 0.5 + 20.0, material=(0.1, 1.0, 1.0))
+    for i in range(n):
+        x = (i % side - 0.5 * (side - 1)) * pitch
+        z = (i // side - 0.5 * (side - 1)) * pitch
+        add_vehicle(s, (x, 1.1, z), yaw=0.3 * i, motor_velocity=motor_velocity)
+    return s
+
+
 def add_ragdoll(s, hip, yaw=0.0):
     """Appends one 14-body humanoid (17 colliders, 7 cone-twist + 6 hinge).  Returns the body ids."""
     sc = 0.42
@@ -431,4 +638,8 @@ def by_name(name):
         return all_shapes_hull()
     if name == "zones":
         return zones()
+    if name == "vehicle":
+        return vehicles(1)
+    if name == "vehicles":
+        return vehicles(16)
     raise KeyError(name)
