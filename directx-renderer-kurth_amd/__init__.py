@@ -69,6 +69,7 @@ EXPORTED_SYMBOLS = [
     "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
     "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_delete_all_constraints_from_body", "mi_delete_body",
     "mi_add_force_field", "mi_set_force_field", "mi_add_trigger", "mi_add_force_field_collider", "mi_add_trigger_collider", "mi_enable_collision_events", "mi_drain_events",
+    "mi_add_cloth", "mi_cloth_set_fixed_vertices", "mi_cloth_set_properties", "mi_set_cloth_iterations", "mi_num_cloths", "mi_cloth_num_particles", "mi_cloth_read",
     "mi_test_physics_interaction", "mi_apply_force_torque", "mi_set_velocity",
     "mi_set_transform", "mi_write_transforms", "mi_write_velocities", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
     "mi_get_stats", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_debug_num_pairs", "mi_debug_read_pairs",
@@ -116,7 +117,7 @@ def load_library():
         lib.mi_last_error.restype = C.c_char_p
         for name in EXPORTED_SYMBOLS:
             fn = getattr(lib, name)
-            if name.startswith("mi_add_") or name in ("mi_num_bodies", "mi_num_colliders", "mi_debug_num_pairs", "mi_debug_num_manifold_slots", "mi_debug_num_colors", "mi_drain_events"):
+            if name.startswith("mi_add_") or name in ("mi_num_bodies", "mi_num_colliders", "mi_debug_num_pairs", "mi_debug_num_manifold_slots", "mi_debug_num_colors", "mi_drain_events", "mi_num_cloths", "mi_cloth_num_particles"):
                 fn.restype = C.c_uint32
         _lib = lib
     return _lib
@@ -236,6 +237,29 @@ class World:
             if n < capacity:
                 break
         return np.concatenate(chunks) if len(chunks) > 1 else chunks[0]
+
+    # ---- cloth (cloth.h:5-60; stepped after the rigid bodies, physics.cpp:1354-1358) ----
+    def add_cloth(self, width, height, grid_x, grid_y, total_mass, stiffness=0.5, damping=0.3, gravity_factor=1.0):
+        return self._id(self.lib.mi_add_cloth(self.w, C.c_float(width), C.c_float(height), C.c_uint32(grid_x), C.c_uint32(grid_y), C.c_float(total_mass),
+                                              C.c_float(stiffness), C.c_float(damping), C.c_float(gravity_factor)))
+
+    def cloth_set_fixed_vertices(self, cloth, pos, rot=(0, 0, 0, 1), move_rigid=False):
+        self._check(self.lib.mi_cloth_set_fixed_vertices(self.w, C.c_uint32(cloth), _f(pos), _f(rot), int(move_rigid)))
+
+    def cloth_set_properties(self, cloth, total_mass, stiffness, damping, gravity_factor):
+        self._check(self.lib.mi_cloth_set_properties(self.w, C.c_uint32(cloth), C.c_float(total_mass), C.c_float(stiffness), C.c_float(damping), C.c_float(gravity_factor)))
+
+    def set_cloth_iterations(self, velocity=0, position=1, drift=0):
+        self._check(self.lib.mi_set_cloth_iterations(self.w, C.c_uint32(velocity), C.c_uint32(position), C.c_uint32(drift)))
+
+    def set_cloth_colour_order(self, on=True):
+        """The device always solves cloth constraints in colour order; present so that a scene instantiates into either world."""
+
+    def cloth_state(self, cloth):
+        n = self.lib.mi_cloth_num_particles(self.w, C.c_uint32(cloth))
+        p = np.zeros((n, 3), np.float32); v = np.zeros((n, 3), np.float32)
+        self._check(self.lib.mi_cloth_read(self.w, C.c_uint32(cloth), _p(p), _p(v)))
+        return p, v
 
     def add_distance_constraint_local(self, a, b, la, lb, distance):
         return self._id(self.lib.mi_add_distance_constraint_local(self.w, a, b, _f(la), _f(lb), C.c_float(distance)))

@@ -100,6 +100,21 @@ struct World
 	struct HField { float force[3]; float pos[3], rot[4]; u32 hasTransform, numColliders; };   // force_field_component (physics.h:182-185) + the entity's transform
 	struct HTrigger { float pos[3], rot[4]; u32 numColliders; };                                 // trigger_component (physics.h:200-203); the callback becomes mi_drain_events
 	std::vector<HField> fields; std::vector<HTrigger> triggers;
+	// cloth_component (cloth.h:5-60): parameters + host mirror of the particle state (authoritative until the first step; refreshed by downloadCloths)
+	struct HClothConstraint { u32 a, b; float restDistance, inverseMassSum; u32 color; };
+	struct HCloth
+	{
+		float width, height, totalMass, stiffness, damping, gravityFactor, oldTotalMass, oldStiffness; u32 gridX, gridY;
+		std::vector<float> pos, prev, vel, invMass;          // 3 n, 3 n, 3 n, n
+		std::vector<HClothConstraint> constraints;            // sorted by colour (stable)
+	};
+	std::vector<HCloth> cloths;
+	bool clothsDirty = true, clothStateOnDevice = false; // dirty: the host mirror changed, upload before the next launch; onDevice: the device copy is newer than the mirror
+	u32 clothIterations[3] = { 0, 1, 0 };  // physics_settings::numCloth{Velocity,Position,Drift}Iterations of the last mi_step (mi_set_cloth_iterations for mi_step_internal)
+	DevBuf<float> clothPlanes; u32 clothStride = 0; // 10 planes of clothStride floats: position xyz, velocity xyz, previous position xyz, inverse mass
+	DevBuf<uint2> clothAB; DevBuf<float2> clothRestIms; DevBuf<float4> clothTemp; DevBuf<uint8_t> clothDescs; DevBuf<u32> clothList;
+	u32 numSmallCloths = 0, maxSmallClothParticles = 0; // cloths that fit the LDS variant come first in clothList
+	void uploadCloths(); void downloadCloths();
 	bool fieldsDirty = true;              // a force changed: re-upload the per-field world-space forces
 	bool collisionBeginEvents = false, collisionEndEvents = false;
 	std::vector<HBody> bodies;
@@ -207,6 +222,8 @@ void launch_broadphase_count(World& w);                    // grid build + pair 
 void launch_broadphase_write(World& w, u32 numPairs);
 void launch_narrowphase(World& w, u32 numPairs);
 void launch_integrate_forces(World& w, float dt);
+void launch_cloth(World& w, float dt);                      // cloth_component::applyWindForce + simulate for every cloth (physics.cpp:1354-1358)
+u32 cloth_lds_particle_limit();
 void launch_apply_fields(World& w);                        // localized + global force fields -> force accumulators (before the force integration)
 void launch_trigger_events(World& w);                      // leave events + table hand-over of the trigger overlap set (after the narrowphase)
 void launch_collision_events(World& w, u32 numPairs);      // begin / end events of this step's manifolds (after the force integration)

@@ -697,6 +697,7 @@ int World::stepInternal(float dt, u32 iters)
 	if (T) MI_CHECK(hipEventRecord(ev[4], stream));
 
 	launch_integrate_velocities(*this, dt);
+	launch_cloth(*this, dt);                               // physics.cpp:1354-1358
 	if (T) MI_CHECK(hipEventRecord(ev[5], stream));
 
 	stats.numRigidBodies = nb; stats.numColliders = nc;
@@ -708,6 +709,105 @@ int World::stepInternal(float dt, u32 iters)
 	return lastError;
 }
 
+
+
+// ---- cloth: host side (cloth.cpp:7-145, 331-347) ---------------------------------------------------------------------
+struct ClothDescHost { u32 firstParticle, numParticles, gridX, gridY, firstConstraint; u32 colorStart[13]; float gravityFactor, damping; }; // = ClothDesc (k_cloth.hip)
+static V3 clothParticlePosition(const World::HCloth& c, float relX, float relY) // cloth.cpp:134-140
+{
+	V3 position = v3(relX * c.width, -relY * c.height, 0.f);
+	position.x -= c.width * 0.5f;
+	float t = position.y; position.y = position.z; position.z = t;
+	return position;
+}
+static void clothRecalculateProperties(World::HCloth& c) // cloth.cpp:331-347
+{
+	u32 numParticles = c.gridX * c.gridY;
+	float invMassPerParticle = numParticles / c.totalMass;
+	for (float& invMass : c.invMass) invMass = (invMass != 0.f) ? invMassPerParticle : 0.f;
+	c.stiffness = clampf(c.stiffness, 0.01f, 1.f);
+	float invStiffness = 1.f / c.stiffness;
+	for (auto& k : c.constraints) k.inverseMassSum = (c.invMass[k.a] + c.invMass[k.b]) * invStiffness;
+}
+void World::downloadCloths()
+{
+	if (!clothStateOnDevice || cloths.empty()) return;
+	resolvePendingFlow();
+	std::vector<float> planes((size_t)9 * clothStride);
+	MI_CHECK(hipMemcpyAsync(planes.data(), clothPlanes.p, sizeof(float) * planes.size(), hipMemcpyDeviceToHost, stream));
+	MI_CHECK(hipStreamSynchronize(stream));
+	size_t first = 0;
+	for (HCloth& c : cloths)
+	{
+		size_t n = (size_t)c.gridX * c.gridY;
+		for (size_t i = 0; i < n; ++i)
+			for (int k = 0; k < 3; ++k)
+			{
+				c.pos[3 * i + k] = planes[(size_t)k * clothStride + first + i];
+				c.vel[3 * i + k] = planes[(size_t)(3 + k) * clothStride + first + i];
+				c.prev[3 * i + k] = planes[(size_t)(6 + k) * clothStride + first + i];
+			}
+		first += n;
+	}
+	clothStateOnDevice = false;
+}
+void World::uploadCloths()
+{
+	for (HCloth& c : cloths)
+		if (c.totalMass != c.oldTotalMass || c.stiffness != c.oldStiffness) { clothRecalculateProperties(c); c.oldTotalMass = c.totalMass; c.oldStiffness = c.stiffness; clothsDirty = true; } // cloth.cpp:198-204
+	if (!clothsDirty) return;
+	downloadCloths();
+	size_t totalParticles = 0, totalConstraints = 0;
+	for (const HCloth& c : cloths) { totalParticles += (size_t)c.gridX * c.gridY; totalConstraints += c.constraints.size(); }
+	clothStride = (u32)totalParticles;
+	std::vector<float> planes((size_t)10 * clothStride);
+	std::vector<uint2> ab(totalConstraints); std::vector<float2> rk(totalConstraints);
+	std::vector<ClothDescHost> descs(cloths.size());
+	std::vector<u32> small, large;
+	size_t firstP = 0, firstC = 0; maxSmallClothParticles = 0;
+	for (size_t ci = 0; ci < cloths.size(); ++ci)
+	{
+		const HCloth& c = cloths[ci];
+		size_t n = (size_t)c.gridX * c.gridY;
+		for (size_t i = 0; i < n; ++i)
+		{
+			for (int k = 0; k < 3; ++k)
+			{
+				planes[(size_t)k * clothStride + firstP + i] = c.pos[3 * i + k];
+				planes[(size_t)(3 + k) * clothStride + firstP + i] = c.vel[3 * i + k];
+				planes[(size_t)(6 + k) * clothStride + firstP + i] = c.prev[3 * i + k];
+			}
+			planes[(size_t)9 * clothStride + firstP + i] = c.invMass[i];
+		}
+		ClothDescHost& d = descs[ci];
+		d.firstParticle = (u32)firstP; d.numParticles = (u32)n; d.gridX = c.gridX; d.gridY = c.gridY; d.firstConstraint = (u32)firstC;
+		d.gravityFactor = c.gravityFactor; d.damping = c.damping;
+		u32 color = 0; d.colorStart[0] = 0;
+		for (size_t k = 0; k < c.constraints.size(); ++k)
+		{
+			const HClothConstraint& e = c.constraints[k];
+			while (color < e.color) d.colorStart[++color] = (u32)k;
+			ab[firstC + k] = make_uint2(e.a, e.b); rk[firstC + k] = make_float2(e.restDistance, e.inverseMassSum);
+		}
+		while (color < 12) d.colorStart[++color] = (u32)c.constraints.size();
+		if (n <= cloth_lds_particle_limit()) { small.push_back((u32)ci); maxSmallClothParticles = std::max(maxSmallClothParticles, (u32)n); } else large.push_back((u32)ci);
+		firstP += n; firstC += c.constraints.size();
+	}
+	numSmallCloths = (u32)small.size();
+	small.insert(small.end(), large.begin(), large.end());
+	clothPlanes.ensure(planes.size(), stream); clothAB.ensure(std::max<size_t>(totalConstraints, 1), stream); clothRestIms.ensure(std::max<size_t>(totalConstraints, 1), stream);
+	clothTemp.ensure(std::max<size_t>(totalConstraints, 1), stream); clothDescs.ensure(sizeof(ClothDescHost) * descs.size(), stream); clothList.ensure(small.size(), stream);
+	MI_CHECK(hipMemcpyAsync(clothPlanes.p, planes.data(), sizeof(float) * planes.size(), hipMemcpyHostToDevice, stream));
+	if (totalConstraints)
+	{
+		MI_CHECK(hipMemcpyAsync(clothAB.p, ab.data(), sizeof(uint2) * ab.size(), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipMemcpyAsync(clothRestIms.p, rk.data(), sizeof(float2) * rk.size(), hipMemcpyHostToDevice, stream));
+	}
+	MI_CHECK(hipMemcpyAsync(clothDescs.p, descs.data(), sizeof(ClothDescHost) * descs.size(), hipMemcpyHostToDevice, stream));
+	MI_CHECK(hipMemcpyAsync(clothList.p, small.data(), sizeof(u32) * small.size(), hipMemcpyHostToDevice, stream));
+	MI_CHECK(hipStreamSynchronize(stream));
+	clothsDirty = false; clothStateOnDevice = false; // both copies are equal until the next launch
+}
 
 // ---- force fields / events: host side ------------------------------------------------------------------------------
 static V3 fieldForceWorld(const World::HField& f) // physics.cpp:767-771
@@ -801,6 +901,7 @@ int World::step(float* timer, const mi_physics_settings* s, float dt)
 	g_currentWorld = this;
 	upload(); uploadJoints();
 	if (lastError) return lastError;
+	clothIterations[0] = s->numClothVelocityIterations; clothIterations[1] = s->numClothPositionIterations; clothIterations[2] = s->numClothDriftIterations;
 	if (s->fixedFrameRate)
 	{
 		const float fixedDt = 1.f / (float)s->frameRate;
@@ -838,7 +939,7 @@ struct mi_world { World w; mi_world(int dev) : w(dev) {} };
 
 namespace
 {
-	const uint32_t SNAPSHOT_MAGIC = 0x4850494Du, SNAPSHOT_VERSION = 2;
+	const uint32_t SNAPSHOT_MAGIC = 0x4850494Du, SNAPSHOT_VERSION = 3;
 	struct BlobWriter
 	{
 		std::vector<uint8_t> bytes;
@@ -889,6 +990,15 @@ namespace
 		out.vec(w.fields); out.vec(w.triggers);
 		uint32_t flags = (w.collisionBeginEvents ? 1u : 0u) | (w.collisionEndEvents ? 2u : 0u); out.pod(flags);
 		out.vec(previousKeys(w, w.triggerSet, w.triggerSetSize, w.triggerCur)); out.vec(previousKeys(w, w.collisionSet, w.collisionSetSize, w.collisionCur));
+		// cloths: parameters, particle state, constraints
+		w.downloadCloths();
+		uint64_t ncl = w.cloths.size(); out.pod(ncl); out.put(w.clothIterations, sizeof(w.clothIterations));
+		for (const World::HCloth& c : w.cloths)
+		{
+			float params[8] = { c.width, c.height, c.totalMass, c.stiffness, c.damping, c.gravityFactor, c.oldTotalMass, c.oldStiffness };
+			out.put(params, sizeof(params)); out.pod(c.gridX); out.pod(c.gridY);
+			out.vec(c.pos); out.vec(c.prev); out.vec(c.vel); out.vec(c.invMass); out.vec(c.constraints);
+		}
 	}
 }
 
@@ -953,7 +1063,18 @@ mi_world* mi_world_restore(const mi_world_desc* desc, const void* buffer, uint64
 	for (JointSet& js : w.joints) { in.vec(js.pods); in.vec(js.a); in.vec(js.b); in.vec(js.alive); }
 	std::vector<u64> triggerKeys, collisionKeys; uint32_t flags = 0;
 	in.vec(w.fields); in.vec(w.triggers); in.pod(flags); in.vec(triggerKeys); in.vec(collisionKeys);
+	uint64_t ncl = 0; in.pod(ncl); in.get(w.clothIterations, sizeof(w.clothIterations));
+	for (uint64_t i = 0; in.ok && i < ncl; ++i)
+	{
+		World::HCloth c; float params[8] = {};
+		in.get(params, sizeof(params)); in.pod(c.gridX); in.pod(c.gridY);
+		c.width = params[0]; c.height = params[1]; c.totalMass = params[2]; c.stiffness = params[3]; c.damping = params[4]; c.gravityFactor = params[5]; c.oldTotalMass = params[6]; c.oldStiffness = params[7];
+		in.vec(c.pos); in.vec(c.prev); in.vec(c.vel); in.vec(c.invMass); in.vec(c.constraints);
+		if (in.ok && (c.pos.size() != 3 * (size_t)c.gridX * c.gridY || c.vel.size() != c.pos.size() || c.prev.size() != c.pos.size() || c.invMass.size() * 3 != c.pos.size())) in.ok = false;
+		w.cloths.push_back(std::move(c));
+	}
 	if (!in.ok) { g_createError = "mi_world_restore: truncated snapshot"; delete world; return nullptr; }
+	w.clothsDirty = true;
 	w.collisionBeginEvents = (flags & 1u) != 0; w.collisionEndEvents = (flags & 2u) != 0;
 	w.topologyDirty = true; w.jointsDirty = true; w.fieldsDirty = true;
 	w.restoredTriggerKeys = triggerKeys; w.restoredCollisionKeys = collisionKeys; // entered into the sets when the first step sizes them
@@ -1120,6 +1241,108 @@ uint32_t mi_drain_events(mi_world* world, mi_event* out, uint32_t capacity)
 	if (n && out) memcpy(out, W->pendingEvents.data(), sizeof(mi_event) * n);
 	W->pendingEvents.erase(W->pendingEvents.begin(), W->pendingEvents.begin() + n);
 	return n;
+}
+
+
+// ---- cloth (cloth.h:5-60) ----
+uint32_t mi_add_cloth(mi_world* world, float width, float height, uint32_t gridSizeX, uint32_t gridSizeY, float totalMass, float stiffness, float damping, float gravityFactor)
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	if (gridSizeX < 2 || gridSizeY < 2 || (uint64_t)gridSizeX * gridSizeY > (1u << 24) || !(totalMass > 0.f) || !(stiffness > 0.f))
+	{ W->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_cloth: needs a grid of at least 2 x 2 particles, positive mass and stiffness"); return 0xFFFFFFFFu; }
+	W->downloadCloths();
+	World::HCloth c;
+	c.width = width; c.height = height; c.totalMass = totalMass; c.stiffness = stiffness; c.damping = damping; c.gravityFactor = gravityFactor;
+	c.oldTotalMass = totalMass; c.oldStiffness = stiffness; c.gridX = gridSizeX; c.gridY = gridSizeY;
+	u32 n = gridSizeX * gridSizeY;
+	float invMassPerParticle = n / totalMass;
+	c.pos.resize(3 * (size_t)n); c.vel.assign(3 * (size_t)n, 0.f); c.invMass.resize(n);
+	for (u32 y = 0; y < gridSizeY; ++y)
+		for (u32 x = 0; x < gridSizeX; ++x)
+		{
+			V3 p = clothParticlePosition(c, x / (float)(gridSizeX - 1), y / (float)(gridSizeY - 1));
+			u32 i = y * gridSizeX + x;
+			c.pos[3 * i] = p.x; c.pos[3 * i + 1] = p.y; c.pos[3 * i + 2] = p.z;
+			c.invMass[i] = (y == 0) ? 0.f : invMassPerParticle; // the upper row is locked (cloth.cpp:29)
+		}
+	c.prev = c.pos;
+	auto add = [&c](u32 a, u32 b, u32 color) // cloth.cpp:320-329
+	{
+		V3 d = v3(c.pos[3 * a] - c.pos[3 * b], c.pos[3 * a + 1] - c.pos[3 * b + 1], c.pos[3 * a + 2] - c.pos[3 * b + 2]);
+		c.constraints.push_back(World::HClothConstraint{ a, b, length(d), (c.invMass[a] + c.invMass[b]) / c.stiffness, color });
+	};
+	for (u32 y = 0; y < gridSizeY; ++y) // cloth.cpp:46-84; colour = constraint family x one parity bit (no two constraints of a colour share a particle)
+		for (u32 x = 0; x < gridSizeX; ++x)
+		{
+			u32 index = y * gridSizeX + x;
+			if (x + 1 < gridSizeX) add(index, index + 1, 0 + (x & 1));
+			if (y + 1 < gridSizeY) add(index, index + gridSizeX, 2 + (y & 1));
+			if (x + 1 < gridSizeX && y + 1 < gridSizeY) { add(index, index + gridSizeX + 1, 4 + (x & 1)); add(index + gridSizeX, index + 1, 6 + (x & 1)); }
+			if (x + 2 < gridSizeX) add(index, index + 2, 8 + ((x >> 1) & 1));
+			if (y + 2 < gridSizeY) add(index, index + gridSizeX * 2, 10 + ((y >> 1) & 1));
+		}
+	std::stable_sort(c.constraints.begin(), c.constraints.end(), [](const World::HClothConstraint& l, const World::HClothConstraint& r) { return l.color < r.color; });
+	W->cloths.push_back(std::move(c)); W->clothsDirty = true;
+	return (uint32_t)W->cloths.size() - 1;
+}
+int mi_cloth_set_fixed_vertices(mi_world* world, uint32_t cloth, const float pos[3], const float rot[4], int moveRigid) // cloth.cpp:90-132
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (cloth >= W->cloths.size() || !pos || !rot) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_cloth_set_fixed_vertices: cloth out of range"); return W->lastError; }
+	W->downloadCloths();
+	World::HCloth& c = W->cloths[cloth];
+	Q4 q = q4(rot[0], rot[1], rot[2], rot[3]); V3 t = v3(pos[0], pos[1], pos[2]);
+	auto P = [&c](u32 i) { return v3(c.pos[3 * i], c.pos[3 * i + 1], c.pos[3 * i + 2]); };
+	auto xform = [&](V3 p) { return q * p + t; };
+	if (moveRigid)
+	{
+		V3 pivot = (c.gridX % 2 == 1) ? P(c.gridX / 2) : (P(c.gridX / 2) + P(c.gridX / 2 - 1)) * 0.5f;
+		V3 currentAxis = normalize(P(c.gridX - 1) - P(0));
+		V3 newAxis = normalize(xform(clothParticlePosition(c, 1.f, 0.f)) - xform(clothParticlePosition(c, 0.f, 0.f)));
+		V3 newPivot = xform(clothParticlePosition(c, 0.5f, 0.f));
+		Q4 deltaRotation = rotateFromTo(currentAxis, newAxis);
+		for (u32 y = 1; y < c.gridY; ++y)
+			for (u32 x = 0; x < c.gridX; ++x)
+			{
+				u32 i = y * c.gridX + x;
+				V3 p = deltaRotation * (P(i) - pivot) + newPivot;
+				c.pos[3 * i] = p.x; c.pos[3 * i + 1] = p.y; c.pos[3 * i + 2] = p.z;
+			}
+	}
+	for (u32 x = 0; x < c.gridX; ++x)
+	{
+		V3 p = xform(clothParticlePosition(c, x / (float)(c.gridX - 1), 0.f));
+		c.pos[3 * x] = p.x; c.pos[3 * x + 1] = p.y; c.pos[3 * x + 2] = p.z;
+	}
+	W->clothsDirty = true;
+	return MI_OK;
+}
+int mi_cloth_set_properties(mi_world* world, uint32_t cloth, float totalMass, float stiffness, float damping, float gravityFactor)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (cloth >= W->cloths.size() || !(totalMass > 0.f)) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_cloth_set_properties: cloth out of range or mass not positive"); return W->lastError; }
+	World::HCloth& c = W->cloths[cloth];
+	c.totalMass = totalMass; c.stiffness = stiffness; c.damping = damping; c.gravityFactor = gravityFactor;
+	W->clothsDirty = true;
+	return MI_OK;
+}
+int mi_set_cloth_iterations(mi_world* world, uint32_t velocityIterations, uint32_t positionIterations, uint32_t driftIterations)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->clothIterations[0] = velocityIterations; W->clothIterations[1] = positionIterations; W->clothIterations[2] = driftIterations;
+	return MI_OK;
+}
+uint32_t mi_num_cloths(mi_world* world) { CHECK_WORLD(0); return (uint32_t)W->cloths.size(); }
+uint32_t mi_cloth_num_particles(mi_world* world, uint32_t cloth) { CHECK_WORLD(0); return cloth < W->cloths.size() ? W->cloths[cloth].gridX * W->cloths[cloth].gridY : 0; }
+int mi_cloth_read(mi_world* world, uint32_t cloth, float* positions3, float* velocities3)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (cloth >= W->cloths.size()) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_cloth_read: cloth out of range"); return W->lastError; }
+	W->downloadCloths();
+	const World::HCloth& c = W->cloths[cloth];
+	if (positions3) memcpy(positions3, c.pos.data(), sizeof(float) * c.pos.size());
+	if (velocities3) memcpy(velocities3, c.vel.data(), sizeof(float) * c.vel.size());
+	return W->lastError;
 }
 
 // ---- constraints (physics.cpp:128-333) ----

@@ -53,6 +53,9 @@ int main()
 			.addComponent<trigger_component>([&](trigger_event e) { (e.type == trigger_event_enter ? enters : leaves)++; if (!(e.trigger == slab)) std::abort(); })
 			.addComponent<collider_component>(collider_component::asAABB(bounding_box::fromCenterRadius(vec3(0.f, 0.f, 0.f), vec3(3.f, 0.25f, 3.f)), mat));
 
+		auto banner = scene.createEntity("banner");
+		banner.addComponent<transform_component>(vec3(-8.f, 9.f, 0.f), quat()).addComponent<cloth_component>(4.f, 3.f, 12u, 9u, 2.f);
+
 		memory_arena arena; physics_settings settings; float timer = 0.f;
 		settings.collisionBeginCallback = [&](const collision_begin_event& e) { ++begins; if (e.colliderA.type > e.colliderB.type) std::abort(); };
 		settings.collisionEndCallback = [&](const collision_end_event&) { ++ends; };
@@ -60,6 +63,7 @@ int main()
 
 		for (auto& e : boxes) { auto t = e.transform(); std::printf("box %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", t.position.x, t.position.y, t.position.z, t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w); }
 		std::printf("events %d %d %d %d\n", enters, leaves, begins, ends);
+		{ auto p = banner.clothPositions(); vec3 c = p.back(); std::printf("cloth %.6f %.6f %.6f\n", c.x, c.y, c.z); }
 		auto t = bob.transform(); std::printf("bob %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", t.position.x, t.position.y, t.position.z, t.rotation.x, t.rotation.y, t.rotation.z, t.rotation.w);
 		return 0;
 	}

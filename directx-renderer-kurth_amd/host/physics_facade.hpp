@@ -74,6 +74,13 @@ namespace mi
 	// force_field_component (physics.h:182-185): on an entity without colliders the force acts on every rigid body, with colliders on
 	// the bodies overlapping them; the entity's transform_component (if it has one) rotates the force
 	struct force_field_component { vec3 force; force_field_component(vec3 f = {}) : force(f) {} };
+	// cloth_component(width, height, gridSizeX, gridSizeY, totalMass, stiffness, damping, gravityFactor), cloth.h:8-9; hung at the entity's transform
+	struct cloth_component
+	{
+		float width, height; uint32_t gridSizeX, gridSizeY; float totalMass, stiffness, damping, gravityFactor;
+		cloth_component(float w, float h, uint32_t gx, uint32_t gy, float mass, float stiff = 0.5f, float damp = 0.3f, float gravity = 1.f)
+			: width(w), height(h), gridSizeX(gx), gridSizeY(gy), totalMass(mass), stiffness(stiff), damping(damp), gravityFactor(gravity) {}
+	};
 	// trigger_event / trigger_component (physics.h:187-203)
 	enum trigger_event_type { trigger_event_enter, trigger_event_leave };
 	struct trigger_event;
@@ -150,6 +157,7 @@ namespace mi
 		uint32_t body() const;
 		transform_component transform() const; // transform_component after the last physicsStep (interpolated)
 		vec3 linearVelocity() const;
+		std::vector<vec3> clothPositions() const; // cloth_component::positions (what cloth_render_component::getRenderData uploads, cloth.cpp:357-363)
 		bool operator==(const scene_entity& o) const { return scene == o.scene && index == o.index; }
 	};
 	struct trigger_event { scene_entity trigger, other; trigger_event_type type; };                                       // physics.h:193-198
@@ -160,7 +168,7 @@ namespace mi
 	{
 		struct entity_record
 		{
-			transform_component transform; bool hasTransform = false; uint32_t body = MI_STATIC_BODY, field = 0xFFFFFFFFu, trigger = 0xFFFFFFFFu;
+			transform_component transform; bool hasTransform = false; uint32_t body = MI_STATIC_BODY, field = 0xFFFFFFFFu, trigger = 0xFFFFFFFFu, cloth = 0xFFFFFFFFu;
 			std::vector<collider_component> pending; std::vector<uint32_t> colliders; trigger_component triggerComponent;
 		};
 
@@ -253,7 +261,11 @@ namespace mi
 	template <typename T, typename... Args> inline scene_entity& scene_entity::addComponent(Args&&... args)
 	{
 		auto& e = scene->entities[index];
-		if constexpr (std::is_same_v<T, transform_component>) { e.transform = transform_component(std::forward<Args>(args)...); e.hasTransform = true; }
+		if constexpr (std::is_same_v<T, transform_component>)
+		{
+			e.transform = transform_component(std::forward<Args>(args)...); e.hasTransform = true;
+			if (e.cloth != 0xFFFFFFFFu) scene->check(mi_cloth_set_fixed_vertices(scene->world, e.cloth, &e.transform.position.x, &e.transform.rotation.x, 1), "setWorldPositionOfFixedVertices"); // scene.h:96-101
+		}
 		else if constexpr (std::is_same_v<T, collider_component>)
 		{
 			collider_component c(std::forward<Args>(args)...);
@@ -264,6 +276,12 @@ namespace mi
 				mi_material m{ c.material.restitution, c.material.friction, c.material.density };
 				scene->registerCollider(index, scene->checkId(mi_add_collider(scene->world, e.body, c.type, c.shape, &m), "mi_add_collider"), c);
 			}
+		}
+		else if constexpr (std::is_same_v<T, cloth_component>)
+		{
+			cloth_component c(std::forward<Args>(args)...);
+			e.cloth = scene->checkId(mi_add_cloth(scene->world, c.width, c.height, c.gridSizeX, c.gridSizeY, c.totalMass, c.stiffness, c.damping, c.gravityFactor), "mi_add_cloth");
+			if (e.hasTransform) scene->check(mi_cloth_set_fixed_vertices(scene->world, e.cloth, &e.transform.position.x, &e.transform.rotation.x, 1), "setWorldPositionOfFixedVertices"); // scene.h:86-94
 		}
 		else if constexpr (std::is_same_v<T, force_field_component> || std::is_same_v<T, trigger_component>)
 		{
@@ -315,6 +333,15 @@ namespace mi
 		scene->check(mi_read_transforms(scene->world, 0, t.data(), n), "mi_read_transforms");
 		const float* p = &t[7 * (size_t)e.body];
 		return transform_component({ p[0], p[1], p[2] }, { p[3], p[4], p[5], p[6] });
+	}
+
+	inline std::vector<vec3> scene_entity::clothPositions() const
+	{
+		uint32_t c = scene->entities[index].cloth;
+		if (c == 0xFFFFFFFFu) throw physics_error("entity has no cloth_component");
+		std::vector<vec3> p(mi_cloth_num_particles(scene->world, c));
+		scene->check(mi_cloth_read(scene->world, c, &p[0].x, nullptr), "mi_cloth_read");
+		return p;
 	}
 
 	inline vec3 scene_entity::linearVelocity() const

@@ -56,6 +56,8 @@ class Scene:
         self.fields = []      # force fields: (force3, pos3 or None, rot4 or None, [(type, shape), ...]); no colliders = global
         self.triggers = []    # triggers: (pos3 or None, rot4 or None, [(type, shape), ...])
         self.collision_events = False
+        self.cloths = []      # (width, height, gridX, gridY, totalMass, stiffness, damping, gravityFactor, pos3, rot4): hung from its locked upper row at (pos, rot)
+        self.cloth_iterations = (0, 1, 0)
         self.joint_edits = []  # (kind, index within kind, [(byte offset, "f4"|"u4", value), ...]): getConstraint(...).field = value after creation
 
     def add_body(self, pos, rot=(0, 0, 0, 1), kinematic=False, gravity_factor=1.0, linear_damping=0.4, angular_damping=0.4):
@@ -77,6 +79,10 @@ class Scene:
     def add_trigger(self, pos=None, rot=None, colliders=()):
         self.triggers.append((pos, rot, list(colliders)))
         return len(self.triggers) - 1
+
+    def add_cloth(self, width, height, grid_x, grid_y, total_mass, pos, rot=(0, 0, 0, 1), stiffness=0.5, damping=0.3, gravity_factor=1.0):
+        self.cloths.append((width, height, grid_x, grid_y, total_mass, stiffness, damping, gravity_factor, tuple(pos), tuple(rot)))
+        return len(self.cloths) - 1
 
     def add_joint(self, kind, a, b, *args):
         self.joints.append((kind, a, b) + args)
@@ -115,6 +121,12 @@ class Scene:
                 world.add_trigger_collider(t, ctype, shape)
         if self.collision_events:
             world.enable_collision_events(True, True)
+        for width, height, gx, gy, mass, stiffness, damping, gravity, pos, rot in self.cloths:
+            c = world.add_cloth(width, height, gx, gy, mass, stiffness, damping, gravity)
+            world.cloth_set_fixed_vertices(c, pos, rot, True)
+        if self.cloths:
+            world.set_cloth_iterations(*self.cloth_iterations)
+            world.set_cloth_colour_order(True)
         return world
 
 
@@ -322,6 +334,22 @@ def _qrot(q, v):
     c = (-q[0], -q[1], -q[2], q[3])
     r = _qmul(_qmul(q, p), c)
     return (r[0], r[1], r[2])
+
+
+def cloths(n=3):
+    """Cloth banners (cloth.cpp) above a small pile of boxes, under a global wind field: a 20 x 20 and a 33 x 17 cloth with all three
+    iteration kinds on (they fit the LDS variant of the kernel), and one 60 x 50 cloth that does not (global-memory variant)."""
+    s = c1_boxes(16)
+    s.name = "cloths_%d" % n
+    s.add_force_field((3.0, 0.5, 1.5))
+    q = _quat_axis_angle((0.0, 1.0, 0.0), 0.6)
+    s.add_cloth(10.0, 10.0, 20, 20, 8.0, (0.0, 14.0, 0.0))
+    if n > 1:
+        s.add_cloth(6.0, 4.0, 33, 17, 3.0, (8.0, 9.0, -3.0), q, stiffness=0.8, damping=0.1)
+    if n > 2:
+        s.add_cloth(12.0, 9.0, 60, 50, 20.0, (-9.0, 16.0, 4.0), q, stiffness=0.3, gravity_factor=0.7)
+    s.cloth_iterations = (2, 3, 1)
+    return s
 
 
 def _rotate_from_to(frm, to):
@@ -638,6 +666,8 @@ def by_name(name):
         return all_shapes_hull()
     if name == "zones":
         return zones()
+    if name == "cloths":
+        return cloths()
     if name == "vehicle":
         return vehicles(1)
     if name == "vehicles":

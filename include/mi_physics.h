@@ -147,6 +147,25 @@ typedef struct mi_event { uint32_t kind, step, a, b, bodyA, bodyB; float positio
  * MI_ERR_CAPACITY (events were lost). */
 uint32_t mi_drain_events(mi_world* w, mi_event* out, uint32_t capacity);
 
+/* ---- cloth (row N4 of SURVEY §8f): cloth_component(width, height, gridSizeX, gridSizeY, totalMass, stiffness = .5, damping = .3,
+ * gravityFactor = 1), cloth.h:8-9.  A grid of particles in the cloth's local frame (x across, -z down, upper row locked) with stretch /
+ * shear / bend distance constraints; every internal step, after the rigid bodies, it receives the global force field as wind and runs
+ * numCloth{Velocity,Position,Drift}Iterations of mi_physics_settings (physics.cpp:1354-1358).  The constraints are solved in a fixed
+ * colour order (12 colours), not the reference's storage order.  Returns the cloth id. */
+uint32_t mi_add_cloth(mi_world* w, float width, float height, uint32_t gridSizeX, uint32_t gridSizeY, float totalMass, float stiffness, float damping, float gravityFactor);
+/* cloth_component::setWorldPositionOfFixedVertices(transform, moveRigid), cloth.h:17: puts the locked upper row at `transform`;
+ * moveRigid also carries the rest of the cloth along rigidly. */
+int mi_cloth_set_fixed_vertices(mi_world* w, uint32_t cloth, const float pos[3], const float rot[4], int moveRigid);
+/* The public fields totalMass / stiffness / damping / gravityFactor (cloth.h:21-24); mass and stiffness changes re-derive the
+ * particle and constraint masses at the next step (cloth.cpp:198-204, 331-347). */
+int mi_cloth_set_properties(mi_world* w, uint32_t cloth, float totalMass, float stiffness, float damping, float gravityFactor);
+/* Cloth iteration counts for mi_step_internal (mi_step takes them from its settings).  Default 0, 1, 0 (physics.h:387-389). */
+int mi_set_cloth_iterations(mi_world* w, uint32_t velocityIterations, uint32_t positionIterations, uint32_t driftIterations);
+uint32_t mi_num_cloths(mi_world* w);
+uint32_t mi_cloth_num_particles(mi_world* w, uint32_t cloth);
+/* Particle positions / velocities, row-major over the grid, n x 3 floats each (either pointer may be NULL). */
+int mi_cloth_read(mi_world* w, uint32_t cloth, float* positions3, float* velocities3);
+
 /* void testPhysicsInteraction(game_scene&, ray, float strength = 1000.f): physics.h:404, physics.cpp:556-628 — the closest rigid-body
  * collider hit by the ray gets force = direction * strength at the hit point.  Returns 1 + the index of the body that was
  * pushed, 0 when the ray hits nothing (this one function does not return a status code). */

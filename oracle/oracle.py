@@ -65,7 +65,7 @@ def _lib(avx2=False):
                      "orc_add_slider_constraint_global", "orc_num_bodies", "orc_num_colliders", "orc_num_pairs", "orc_num_contacts",
                      "orc_num_collisions", "orc_sorting_axis_used", "orc_sorting_axis_next", "orc_num_contact_slots",
                      "orc_narrowphase_ordered", "orc_schedule", "orc_read_slot_counts", "orc_add_hull_geometry", "orc_test_physics_interaction",
-                     "orc_add_force_field", "orc_add_trigger", "orc_add_force_field_collider", "orc_add_trigger_collider", "orc_drain_events"):
+                     "orc_add_cloth", "orc_cloth_num_particles", "orc_cloth_num_constraints", "orc_add_force_field", "orc_add_trigger", "orc_add_force_field_collider", "orc_add_trigger_collider", "orc_drain_events"):
             getattr(lib, name).restype = C.c_uint32
         _libs[key] = lib
     return _libs[key]
@@ -144,6 +144,36 @@ class OracleWorld:
         out = np.zeros(capacity, EVENT_DTYPE)
         n = self.lib.orc_drain_events(self.w, _p(out), C.c_uint32(capacity))
         return out[:n]
+
+    # ---- cloth (cloth.h:5-60; stepped after the rigid bodies, physics.cpp:1354-1358) ----
+    def add_cloth(self, width, height, grid_x, grid_y, total_mass, stiffness=0.5, damping=0.3, gravity_factor=1.0):
+        return self.lib.orc_add_cloth(self.w, C.c_float(width), C.c_float(height), C.c_uint32(grid_x), C.c_uint32(grid_y), C.c_float(total_mass),
+                                      C.c_float(stiffness), C.c_float(damping), C.c_float(gravity_factor))
+
+    def cloth_set_fixed_vertices(self, cloth, pos, rot=(0, 0, 0, 1), move_rigid=False):
+        assert self.lib.orc_cloth_set_fixed_vertices(self.w, C.c_uint32(cloth), _f(pos), _f(rot), int(move_rigid)) == 0
+
+    def cloth_set_properties(self, cloth, total_mass, stiffness, damping, gravity_factor):
+        assert self.lib.orc_cloth_set_properties(self.w, C.c_uint32(cloth), C.c_float(total_mass), C.c_float(stiffness), C.c_float(damping), C.c_float(gravity_factor)) == 0
+
+    def set_cloth_iterations(self, velocity=0, position=1, drift=0):
+        self.lib.orc_set_cloth_iterations(self.w, C.c_uint32(velocity), C.c_uint32(position), C.c_uint32(drift))
+
+    def set_cloth_colour_order(self, on=True):
+        """Gauss-Seidel order of the cloth constraints: the reference's storage order (False) or the device's colour order (True)."""
+        self.lib.orc_set_cloth_colour_order(self.w, int(on))
+
+    def cloth_state(self, cloth):
+        n = self.lib.orc_cloth_num_particles(self.w, C.c_uint32(cloth))
+        p = np.zeros((n, 3), np.float32); v = np.zeros((n, 3), np.float32)
+        assert self.lib.orc_cloth_read(self.w, C.c_uint32(cloth), _p(p), _p(v)) == 0
+        return p, v
+
+    def cloth_constraints(self, cloth):
+        n = self.lib.orc_cloth_num_constraints(self.w, C.c_uint32(cloth))
+        c = np.zeros(n, np.dtype([("a", "<u4"), ("b", "<u4"), ("restDistance", "<f4"), ("inverseMassSum", "<f4")])); col = np.zeros(n, np.uint32)
+        self.lib.orc_cloth_read_constraints(self.w, C.c_uint32(cloth), _p(c), _p(col))
+        return c, col
 
     def add_distance_constraint_local(self, a, b, la, lb, distance):
         return self.lib.orc_add_distance_constraint_local(self.w, a, b, _f(la), _f(lb), C.c_float(distance))

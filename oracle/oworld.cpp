@@ -7,6 +7,7 @@
 #include "onarrow.h"
 #include "oconstraints.h"
 #include "owide.h"
+#include "ocloth.h"
 #include <vector>
 #include <cstdio>
 
@@ -81,6 +82,9 @@ struct world
 	bool collisionBeginEvents = false, collisionEndEvents = false;  // physics_settings::collisionBeginCallback / collisionEndCallback set
 	std::vector<event_record> events;                               // callbacks in call order, drained by orc_drain_events
 	u32 stepIndex = 0;
+	std::vector<cloth> cloths;                                      // cloth_component, stepped after the rigid bodies (physics.cpp:1354-1358)
+	u32 clothIterations[3] = { 0, 1, 0 };                           // physics_settings::numCloth{Velocity,Position,Drift}Iterations (physics.h:387-389)
+	bool clothColourOrder = false;                                  // Gauss-Seidel order of the cloth constraints: storage (reference) or colour (device)
 	u32 zoneTested[36] = {}, zoneHit[36] = {};                      // overlap checks per type pair (typeA * 6 + typeB), for test coverage reports
 
 	// sap_context (collision_broad.cpp:20-24)
@@ -795,6 +799,12 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 	}
 
 	for (u32 i = 0; i < numRigidBodies; ++i) { integrateVelocity(w.bodies[i], w.rbGlobal[i], w.bodies[i].transform1, dt); }
+
+	for (cloth& c : w.cloths) // physics.cpp:1354-1358
+	{
+		c.applyWindForce(globalForce);
+		c.simulate(w.clothIterations[0], w.clothIterations[1], w.clothIterations[2], dt, w.clothColourOrder);
+	}
 }
 
 // physics.cpp:1364-1413
@@ -808,6 +818,7 @@ static void physicsStep(world& w, float& timer, const physics_settings& settings
 		if (timer >= physicsFixedTimeStep)
 		{
 			for (body& b : w.bodies) { b.transform0 = b.transform1; }
+			w.clothIterations[0] = settings.numClothVelocityIterations; w.clothIterations[1] = settings.numClothPositionIterations; w.clothIterations[2] = settings.numClothDriftIterations;
 			while (timer >= physicsFixedTimeStep && physicsIterations++ < settings.maxPhysicsIterationsPerFrame)
 			{
 				physicsStepInternal(w, settings.numRigidSolverIterations, mode, physicsFixedTimeStep);
@@ -826,6 +837,7 @@ static void physicsStep(world& w, float& timer, const physics_settings& settings
 	}
 	else
 	{
+		w.clothIterations[0] = settings.numClothVelocityIterations; w.clothIterations[1] = settings.numClothPositionIterations; w.clothIterations[2] = settings.numClothDriftIterations;
 		physicsStepInternal(w, settings.numRigidSolverIterations, mode, dt);
 		for (body& b : w.bodies) { b.transform = b.transform1; }
 	}
@@ -934,6 +946,45 @@ void orc_overlap_ordered(const void* colliders64, const u32* pairs2, u32 numPair
 {
 	const collider_union* cols = (const collider_union*)colliders64;
 	for (u32 i = 0; i < numPairs; ++i) outOverlaps[i] = overlapColliders(cols[pairs2[2 * i]], cols[pairs2[2 * i + 1]]) ? 1 : 0;
+}
+// ---- cloth (cloth.h:5-60) ----
+u32 orc_add_cloth(world* w, float width, float height, u32 gridSizeX, u32 gridSizeY, float totalMass, float stiffness, float damping, float gravityFactor)
+{
+	w->cloths.emplace_back(width, height, gridSizeX, gridSizeY, totalMass, stiffness, damping, gravityFactor);
+	return (u32)w->cloths.size() - 1;
+}
+int orc_cloth_set_fixed_vertices(world* w, u32 c, const float* pos, const float* rot, int moveRigid)
+{
+	if (c >= w->cloths.size()) return 1;
+	w->cloths[c].setWorldPositionOfFixedVertices(makeTrs(pos, rot), moveRigid != 0);
+	return 0;
+}
+int orc_cloth_set_properties(world* w, u32 c, float totalMass, float stiffness, float damping, float gravityFactor)
+{
+	if (c >= w->cloths.size()) return 1;
+	cloth& cl = w->cloths[c]; cl.totalMass = totalMass; cl.stiffness = stiffness; cl.damping = damping; cl.gravityFactor = gravityFactor;
+	return 0;
+}
+void orc_set_cloth_iterations(world* w, u32 velocityIterations, u32 positionIterations, u32 driftIterations) { w->clothIterations[0] = velocityIterations; w->clothIterations[1] = positionIterations; w->clothIterations[2] = driftIterations; }
+void orc_set_cloth_colour_order(world* w, int on) { w->clothColourOrder = on != 0; }
+u32 orc_cloth_num_particles(world* w, u32 c) { return c < w->cloths.size() ? w->cloths[c].gridSizeX * w->cloths[c].gridSizeY : 0; }
+u32 orc_cloth_num_constraints(world* w, u32 c) { return c < w->cloths.size() ? (u32)w->cloths[c].constraints.size() : 0; }
+int orc_cloth_read(world* w, u32 c, float* positions3, float* velocities3)
+{
+	if (c >= w->cloths.size()) return 1;
+	const cloth& cl = w->cloths[c];
+	for (size_t i = 0; i < cl.positions.size(); ++i)
+	{
+		if (positions3) { positions3[3 * i] = cl.positions[i].x; positions3[3 * i + 1] = cl.positions[i].y; positions3[3 * i + 2] = cl.positions[i].z; }
+		if (velocities3) { velocities3[3 * i] = cl.velocities[i].x; velocities3[3 * i + 1] = cl.velocities[i].y; velocities3[3 * i + 2] = cl.velocities[i].z; }
+	}
+	return 0;
+}
+void orc_cloth_read_constraints(world* w, u32 c, void* out16, u32* outColour) // {a, b, restDistance, inverseMassSum} + colour per constraint, storage order
+{
+	const cloth& cl = w->cloths[c];
+	memcpy(out16, cl.constraints.data(), sizeof(cloth_constraint) * cl.constraints.size());
+	memcpy(outColour, cl.colour.data(), sizeof(u32) * cl.colour.size());
 }
 void orc_enable_collision_events(world* w, int begin, int end) { w->collisionBeginEvents = begin != 0; w->collisionEndEvents = end != 0; }
 u32 orc_drain_events(world* w, void* out60, u32 capacity)

@@ -30,7 +30,8 @@ def test_facade_matches_ctypes_world(tmp_path, mi):
     exe = build_example(tmp_path)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     lines = out.strip().splitlines()
-    got = np.array([[float(x) for x in line.split()[1:]] for line in lines if not line.startswith("events")], np.float32)
+    got = np.array([[float(x) for x in line.split()[1:]] for line in lines if line.split()[0] in ("box", "bob")], np.float32)
+    got_cloth = np.array([float(x) for x in [line for line in lines if line.startswith("cloth")][0].split()[1:]], np.float32)
     got_events = [int(x) for x in [line for line in lines if line.startswith("events")][0].split()[1:]]
 
     w = mi.World()
@@ -57,8 +58,11 @@ def test_facade_matches_ctypes_world(tmp_path, mi):
     trig = w.add_trigger(pos=(0, 3, 0), rot=(0, 0, 0, 1))
     w.add_trigger_collider(trig, mi.AABB, [-3, -0.25, -3, 3, 0.25, 3])
     w.enable_collision_events()
+    banner = w.add_cloth(4.0, 3.0, 12, 9, 2.0)
+    w.cloth_set_fixed_vertices(banner, (-8, 9, 0), (0, 0, 0, 1), True)
     for _ in range(120):
         w.step(1.0 / 60.0, mi.Settings())
+    np.testing.assert_allclose(w.cloth_state(banner)[0][-1], got_cloth, atol=2e-6)
     ev = w.drain_events()
     assert got_events == np.bincount(ev["kind"], minlength=4).tolist() and got_events[0] >= 2 and got_events[2] >= 8
     t = w.transforms(0)[ids + [bob]]

@@ -298,3 +298,33 @@ def test_zones_scene_reaches_every_overlap_pair(oracle):
     miss[3, 3] = 1  # two world-space AABBs that pass the broadphase overlap by definition
     assert (hit[iu] > 0).all() and (miss[iu] > 0).all(), (tested, hit)
     assert kinds == {0, 1, 2, 3}
+
+
+def test_cloth_oracle_orders_and_invariants(oracle):
+    """The cloth restatement (cloth.cpp): the reference's storage order and the device's colour order are both Gauss-Seidel sweeps over the
+    same constraints — each colour is conflict-free, both keep the locked row and hold the stretch constraints' rest lengths within the
+    solver's slack while the cloth swings down from its horizontal start, and the two trajectories stay close."""
+    res = {}
+    for colour in (False, True):
+        w = oracle.OracleWorld()
+        b = w.add_body((0, 100, 0)); w.add_collider(b, oracle.SPHERE, (0, 0, 0, 0.5), (0.1, 0.5, 1.0))   # the step needs one rigid body (physics.cpp:1184)
+        c = w.add_cloth(10.0, 10.0, 20, 20, 8.0)
+        w.cloth_set_fixed_vertices(c, (0, 12, 0), (0, 0, 0, 1), True)
+        w.set_cloth_iterations(1, 4, 1)
+        w.set_cloth_colour_order(colour)
+        top = w.cloth_state(c)[0][:20].copy()
+        for _ in range(240):
+            w.step_internal(1.0 / 120.0, 1)
+        p, v = w.cloth_state(c)
+        cons, col = w.cloth_constraints(c)
+        assert np.array_equal(p[:20], top)
+        stretch = cons[col < 4]
+        length = np.linalg.norm(p[stretch["a"]] - p[stretch["b"]], axis=1)
+        assert np.abs(length / stretch["restDistance"] - 1.0).max() < 0.15
+        assert np.isfinite(v).all() and 1.0 < np.abs(v).max() < 30.0
+        res[colour] = p
+        for k in range(12):
+            ids = np.concatenate([cons["a"][col == k], cons["b"][col == k]])
+            assert len(ids) == len(np.unique(ids))
+    assert np.abs(res[True] - res[False]).max() < 0.25
+    assert res[True][:, 1].min() < 6.0                     # the free edge has swung down from the bar at y = 12
