@@ -69,6 +69,7 @@ EXPORTED_SYMBOLS = [
     "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
     "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_delete_all_constraints_from_body", "mi_delete_body",
     "mi_add_force_field", "mi_set_force_field", "mi_add_trigger", "mi_add_force_field_collider", "mi_add_trigger_collider", "mi_enable_collision_events", "mi_drain_events",
+    "mi_set_heightmap", "mi_heightmap_set_chunk", "mi_heightmap_update", "mi_heightmap_height_at",
     "mi_add_cloth", "mi_cloth_set_fixed_vertices", "mi_cloth_set_properties", "mi_set_cloth_iterations", "mi_num_cloths", "mi_cloth_num_particles", "mi_cloth_read",
     "mi_test_physics_interaction", "mi_apply_force_torque", "mi_set_velocity",
     "mi_set_transform", "mi_write_transforms", "mi_write_velocities", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
@@ -115,6 +116,7 @@ def load_library():
         lib.mi_world_restore.restype = C.c_void_p
         lib.mi_snapshot_size.restype = C.c_uint64
         lib.mi_last_error.restype = C.c_char_p
+        lib.mi_heightmap_height_at.restype = C.c_float
         for name in EXPORTED_SYMBOLS:
             fn = getattr(lib, name)
             if name.startswith("mi_add_") or name in ("mi_num_bodies", "mi_num_colliders", "mi_debug_num_pairs", "mi_debug_num_manifold_slots", "mi_debug_num_colors", "mi_drain_events", "mi_num_cloths", "mi_cloth_num_particles"):
@@ -237,6 +239,21 @@ class World:
             if n < capacity:
                 break
         return np.concatenate(chunks) if len(chunks) > 1 else chunks[0]
+
+    # ---- heightmap terrain (heightmap_collider.h:127-152) ----
+    def set_heightmap(self, chunks_per_dim, chunk_size, material, min_corner, amplitude_scale):
+        m = Material(*material)
+        self._check(self.lib.mi_set_heightmap(self.w, C.c_uint32(chunks_per_dim), C.c_float(chunk_size), C.byref(m), _f(min_corner), C.c_float(amplitude_scale)))
+
+    def heightmap_set_chunk(self, x, z, heights):
+        h = np.ascontiguousarray(heights, np.uint16).reshape(129, 129)
+        self._check(self.lib.mi_heightmap_set_chunk(self.w, C.c_uint32(x), C.c_uint32(z), _p(h)))
+
+    def heightmap_update(self, min_corner, amplitude_scale):
+        self._check(self.lib.mi_heightmap_update(self.w, _f(min_corner), C.c_float(amplitude_scale)))
+
+    def heightmap_height_at(self, x, z):
+        return float(self.lib.mi_heightmap_height_at(self.w, C.c_float(x), C.c_float(z)))
 
     # ---- cloth (cloth.h:5-60; stepped after the rigid bodies, physics.cpp:1354-1358) ----
     def add_cloth(self, width, height, grid_x, grid_y, total_mass, stiffness=0.5, damping=0.3, gravity_factor=1.0):

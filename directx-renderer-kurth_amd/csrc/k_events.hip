@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_collision_begin(u32* __restrict__ count
 	const float4* __restrict__ vel, const float4* __restrict__ cog, u32 nb, PairSetView set, EventSink sink, u32 emit)
 {
 	u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
-	if (slot >= counters[CTR_NUM_VALID]) return;
+	if (slot >= counters[CTR_BUCKET_START + 62]) return; // pair manifolds only: terrain contacts raise no events (physics.cpp:1049: colliderB < numColliders)
 	uint4 ids = manifolds[slot].ids;
 	u32 count = ids.z;
 	if (!count) return;

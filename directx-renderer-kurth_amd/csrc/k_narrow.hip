@@ -1186,7 +1186,11 @@ __global__ void __launch_bounds__(64) k_zone_overlap(u32* __restrict__ counters,
 
 void launch_narrowphase(World& w, u32 numPairs)
 {
-	if (!numPairs) return;
+	if (!numPairs)
+	{
+		if (w.terrainChunksPerDim) hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p); // no pairs: all buckets empty, the terrain contacts start at slot 0
+		return;
+	}
 	dim3 grid((numPairs + 255) / 256), block(256);
 	hipLaunchKernelGGL(k_classify, grid, block, 0, w.stream, w.dCounters.p, w.nb, w.pairs.p, w.colWorld.p, w.pairKey.p, (u64*)w.pairsSorted.p + numPairs);
 	// sort (bucket key, packed pair): unsorted packed pairs live in the upper half of pairsSorted, sorted ones in the lower half

@@ -5,6 +5,7 @@
 #include "../../include/mi_physics.h"
 #include <vector>
 #include <string>
+#include <algorithm>
 
 // ---- persistent joint PODs: byte-for-byte the reference's structs (constraints.h:73-80,129-135,175-183,229-257,346-380,497-520)
 struct mi_distance_constraint { float localAnchorA[3], localAnchorB[3], globalLength; };
@@ -84,6 +85,8 @@ enum
 	CTR_REGION_MINMAX = 410,// 2 words: running min / max of x (order-preserving integer encoding) for the next range
 	CTR_EVENT_COUNT = 416,  // append cursor of the event ring (trigger enter/leave, collision begin/end), reset by mi_drain_events
 	CTR_EVENT_OVERFLOW = 417,// bit 0: the event ring was full, events were dropped; bit 1: a pair-set table was full
+	CTR_TERRAIN_BASE = 418, // first manifold slot of the terrain contacts (= number of pair manifold slots)
+	CTR_TERRAIN_OVERFLOW = 419,// more terrain contacts than slots: contacts were dropped (the host fails the world)
 	CTR_WORDS = 512,
 };
 #define MI_NUM_SCHEDULE_KEYS ((MI_MAX_COLORS + 1) * 4)
@@ -100,6 +103,12 @@ struct World
 	struct HField { float force[3]; float pos[3], rot[4]; u32 hasTransform, numColliders; };   // force_field_component (physics.h:182-185) + the entity's transform
 	struct HTrigger { float pos[3], rot[4]; u32 numColliders; };                                 // trigger_component (physics.h:200-203); the callback becomes mi_drain_events
 	std::vector<HField> fields; std::vector<HTrigger> triggers;
+	// heightmap_collider_component (heightmap_collider.h:127-152): chunksPerDim x chunksPerDim chunks of 129 x 129 uint16 heights
+	u32 terrainChunksPerDim = 0, terrainSlotsPerCollider = 8; float terrainChunkSize = 0.f, terrainAmplitude = 1.f, terrainMinCorner[3] = { 0.f, 0.f, 0.f }, terrainMaterial[3] = { 0.f, 0.f, 0.f };
+	std::vector<uint16_t> hTerrainHeights; std::vector<u32> hTerrainValid;
+	DevBuf<uint16_t> terrainHeights; DevBuf<u32> terrainValid, terrainCounts, terrainOffsets;
+	u32 terrainSlotCap() const { return terrainChunksPerDim ? std::max(8192u, terrainSlotsPerCollider * (u32)colliders.size()) : 0u; }
+	u32 prevTruePairs = 0;                // broadphase overlaps of the last step (prevNumPairs counts the terrain slots too)
 	// cloth_component (cloth.h:5-60): parameters + host mirror of the particle state (authoritative until the first step; refreshed by downloadCloths)
 	struct HClothConstraint { u32 a, b; float restDistance, inverseMassSum; u32 color; };
 	struct HCloth
@@ -222,6 +231,7 @@ void launch_broadphase_count(World& w);                    // grid build + pair 
 void launch_broadphase_write(World& w, u32 numPairs);
 void launch_narrowphase(World& w, u32 numPairs);
 void launch_integrate_forces(World& w, float dt);
+void launch_heightmap(World& w, u32 numPairs, u32 slotCap);  // terrain contacts appended after the pair manifolds (physics.cpp:1236-1249)
 void launch_cloth(World& w, float dt);                      // cloth_component::applyWindForce + simulate for every cloth (physics.cpp:1354-1358)
 u32 cloth_lds_particle_limit();
 void launch_apply_fields(World& w);                        // localized + global force fields -> force accumulators (before the force integration)

@@ -575,9 +575,9 @@ void World::countPreviousStep()
 	bool had = prevNumPairs != 0;
 	stats.numCollisions = had ? hCounters[CTR_NUM_MANIFOLDS] : 0; stats.numContacts = had ? hCounters[CTR_NUM_CONTACTS] : 0;
 	stats.numColors = had ? hCounters[CTR_NUM_COLORS] : 0; stats.flowProbes = hCounters[CTR_FLOW_PROBES];
-	stats.numBroadphaseOverlaps = prevNumPairs;
+	stats.numBroadphaseOverlaps = prevTruePairs;
 	lastNumManifolds = stats.numCollisions;
-	sumContacts += stats.numContacts; sumManifolds += stats.numCollisions; sumColors += stats.numColors; sumPairs += prevNumPairs; sumProbes += stats.flowProbes; sumSteps++;
+	sumContacts += stats.numContacts; sumManifolds += stats.numCollisions; sumColors += stats.numColors; sumPairs += prevTruePairs; sumProbes += stats.flowProbes; sumSteps++;
 }
 
 // Bring hCounters (and the statistics) up to date with the device: needed by whoever looks at the last step's schedule or counts
@@ -588,7 +588,7 @@ void World::refreshCounters()
 	resolvePendingFlow();
 	readCounters(*this);
 	if (!prevNumPairs) { memset(hCounters + CTR_KEY_START, 0, sizeof(u32) * (MI_NUM_SCHEDULE_KEYS + 1)); hCounters[CTR_NUM_MANIFOLDS] = 0; hCounters[CTR_NUM_VALID] = 0; hCounters[CTR_NUM_COLORS] = 0; }
-	hCounters[CTR_NUM_PAIRS] = prevNumPairs; // (the pair count of the finished step; the device word is the same until the next broadphase)
+	hCounters[CTR_NUM_PAIRS] = prevTruePairs; // (the pair count of the finished step; the device word is the same until the next broadphase)
 	countPreviousStep();
 }
 
@@ -630,13 +630,16 @@ int World::stepInternal(float dt, u32 iters)
 	flowPending = false;
 	countPreviousStep();                                   // the counters just read hold the previous step's colour / contact counts
 	u32 prevColors = stats.numInternalSteps ? stats.numColors : 0xFFFFu;
-	u32 numPairs = hCounters[CTR_NUM_PAIRS];
+	if (hCounters[CTR_TERRAIN_OVERFLOW]) { fail(MI_ERR_CAPACITY, "more terrain contacts than manifold slots: contacts were dropped (raise MI_TERRAIN_SLOTS_PER_COLLIDER)"); return lastError; }
+	const u32 truePairs = hCounters[CTR_NUM_PAIRS];
+	const u32 numPairs = truePairs + terrainSlotCap();     // bound on the manifold slots of the step: pair slots + room for the terrain contacts
 	ensurePairBuffers(*this, numPairs);
 	ensureEventBuffers(numPairs);
-	launch_broadphase_write(*this, numPairs);
+	launch_broadphase_write(*this, truePairs);
 	if (T) MI_CHECK(hipEventRecord(ev[1], stream));
 
-	launch_narrowphase(*this, numPairs);
+	launch_narrowphase(*this, truePairs);
+	launch_heightmap(*this, truePairs, numPairs);          // physics.cpp:1236-1249
 	launch_trigger_events(*this);                          // physics.cpp:1255 (handleNonCollisionInteractions)
 	if (T) MI_CHECK(hipEventRecord(ev[2], stream));
 
@@ -701,7 +704,7 @@ int World::stepInternal(float dt, u32 iters)
 	if (T) MI_CHECK(hipEventRecord(ev[5], stream));
 
 	stats.numRigidBodies = nb; stats.numColliders = nc;
-	prevNumPairs = numPairs;
+	prevNumPairs = numPairs; prevTruePairs = truePairs;
 	stats.numInternalSteps++;
 	if (!noSync2) countPreviousStep(); // this step's counts are on the host already (hCounters comes from its own second read)
 	u32 nj = 0; for (auto& js : joints) nj += (u32)js.order.size();
@@ -939,7 +942,7 @@ struct mi_world { World w; mi_world(int dev) : w(dev) {} };
 
 namespace
 {
-	const uint32_t SNAPSHOT_MAGIC = 0x4850494Du, SNAPSHOT_VERSION = 3;
+	const uint32_t SNAPSHOT_MAGIC = 0x4850494Du, SNAPSHOT_VERSION = 4;
 	struct BlobWriter
 	{
 		std::vector<uint8_t> bytes;
@@ -990,6 +993,9 @@ namespace
 		out.vec(w.fields); out.vec(w.triggers);
 		uint32_t flags = (w.collisionBeginEvents ? 1u : 0u) | (w.collisionEndEvents ? 2u : 0u); out.pod(flags);
 		out.vec(previousKeys(w, w.triggerSet, w.triggerSetSize, w.triggerCur)); out.vec(previousKeys(w, w.collisionSet, w.collisionSetSize, w.collisionCur));
+		// heightmap terrain
+		out.pod(w.terrainChunksPerDim); out.pod(w.terrainChunkSize); out.pod(w.terrainAmplitude); out.put(w.terrainMinCorner, 12); out.put(w.terrainMaterial, 12);
+		out.vec(w.hTerrainHeights); out.vec(w.hTerrainValid);
 		// cloths: parameters, particle state, constraints
 		w.downloadCloths();
 		uint64_t ncl = w.cloths.size(); out.pod(ncl); out.put(w.clothIterations, sizeof(w.clothIterations));
@@ -1063,6 +1069,20 @@ mi_world* mi_world_restore(const mi_world_desc* desc, const void* buffer, uint64
 	for (JointSet& js : w.joints) { in.vec(js.pods); in.vec(js.a); in.vec(js.b); in.vec(js.alive); }
 	std::vector<u64> triggerKeys, collisionKeys; uint32_t flags = 0;
 	in.vec(w.fields); in.vec(w.triggers); in.pod(flags); in.vec(triggerKeys); in.vec(collisionKeys);
+	in.pod(w.terrainChunksPerDim); in.pod(w.terrainChunkSize); in.pod(w.terrainAmplitude); in.get(w.terrainMinCorner, 12); in.get(w.terrainMaterial, 12);
+	in.vec(w.hTerrainHeights); in.vec(w.hTerrainValid);
+	if (in.ok && w.terrainChunksPerDim)
+	{
+		size_t chunks = (size_t)w.terrainChunksPerDim * w.terrainChunksPerDim;
+		if (w.hTerrainValid.size() != chunks || w.hTerrainHeights.size() != chunks * 129 * 129) in.ok = false;
+		else
+		{
+			w.terrainHeights.ensure(w.hTerrainHeights.size(), w.stream); w.terrainValid.ensure(chunks, w.stream);
+			MI_CHECK(hipMemcpyAsync(w.terrainHeights.p, w.hTerrainHeights.data(), sizeof(uint16_t) * w.hTerrainHeights.size(), hipMemcpyHostToDevice, w.stream));
+			MI_CHECK(hipMemcpyAsync(w.terrainValid.p, w.hTerrainValid.data(), sizeof(u32) * chunks, hipMemcpyHostToDevice, w.stream));
+			MI_CHECK(hipStreamSynchronize(w.stream));
+		}
+	}
 	uint64_t ncl = 0; in.pod(ncl); in.get(w.clothIterations, sizeof(w.clothIterations));
 	for (uint64_t i = 0; in.ok && i < ncl; ++i)
 	{
@@ -1243,6 +1263,60 @@ uint32_t mi_drain_events(mi_world* world, mi_event* out, uint32_t capacity)
 	return n;
 }
 
+
+
+// ---- heightmap terrain (heightmap_collider.h:127-152, heightmap_collider.cpp:5-38) ----
+int mi_set_heightmap(mi_world* world, uint32_t chunksPerDim, float chunkSize, const mi_material* material, const float minCorner[3], float amplitudeScale)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (!chunksPerDim || chunksPerDim > 256 || !(chunkSize > 0.f) || !(amplitudeScale > 0.f) || !material || !minCorner) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_set_heightmap: 1..256 chunks per dimension, positive chunk size and amplitude"); return W->lastError; }
+	W->resolvePendingFlow();
+	W->terrainChunksPerDim = chunksPerDim; W->terrainChunkSize = chunkSize; W->terrainAmplitude = amplitudeScale;
+	memcpy(W->terrainMinCorner, minCorner, 12); W->terrainMaterial[0] = material->restitution; W->terrainMaterial[1] = material->friction; W->terrainMaterial[2] = material->density;
+	size_t chunks = (size_t)chunksPerDim * chunksPerDim;
+	W->hTerrainHeights.assign(chunks * 129 * 129, 0); W->hTerrainValid.assign(chunks, 0);
+	W->terrainHeights.ensure(W->hTerrainHeights.size(), W->stream); W->terrainValid.ensure(chunks, W->stream);
+	MI_CHECK(hipMemsetAsync(W->terrainValid.p, 0, sizeof(u32) * chunks, W->stream));
+	if (const char* e = getenv("MI_TERRAIN_SLOTS_PER_COLLIDER")) W->terrainSlotsPerCollider = (u32)std::max(1, atoi(e));
+	return W->lastError;
+}
+int mi_heightmap_set_chunk(mi_world* world, uint32_t x, uint32_t z, const uint16_t* heights129x129) // heightmap_collider_chunk::setHeights
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (!W->terrainChunksPerDim || x >= W->terrainChunksPerDim || z >= W->terrainChunksPerDim || !heights129x129) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_heightmap_set_chunk: chunk out of range (mi_set_heightmap first)"); return W->lastError; }
+	W->resolvePendingFlow();
+	size_t chunk = (size_t)z * W->terrainChunksPerDim + x, n = 129 * 129;
+	memcpy(W->hTerrainHeights.data() + chunk * n, heights129x129, sizeof(uint16_t) * n);
+	W->hTerrainValid[chunk] = 1;
+	MI_CHECK(hipMemcpyAsync(W->terrainHeights.p + chunk * n, W->hTerrainHeights.data() + chunk * n, sizeof(uint16_t) * n, hipMemcpyHostToDevice, W->stream));
+	MI_CHECK(hipMemcpyAsync(W->terrainValid.p + chunk, W->hTerrainValid.data() + chunk, sizeof(u32), hipMemcpyHostToDevice, W->stream));
+	MI_CHECK(hipStreamSynchronize(W->stream));
+	return W->lastError;
+}
+int mi_heightmap_update(mi_world* world, const float minCorner[3], float amplitudeScale) // heightmap_collider_component::update
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (!W->terrainChunksPerDim || !minCorner || !(amplitudeScale > 0.f)) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_heightmap_update: no heightmap, or amplitude not positive"); return W->lastError; }
+	memcpy(W->terrainMinCorner, minCorner, 12); W->terrainAmplitude = amplitudeScale;
+	return MI_OK;
+}
+float mi_heightmap_height_at(mi_world* world, float wx, float wz) // heightmap_collider_component::getHeightAt: -FLT_MAX outside the terrain
+{
+	CHECK_WORLD(-MI_FLT_MAX);
+	if (!W->terrainChunksPerDim) return -MI_FLT_MAX;
+	float invChunkSize = 1.f / W->terrainChunkSize, heightScale = W->terrainAmplitude / 65535;
+	float cx = (wx - W->terrainMinCorner[0]) * invChunkSize, cz = (wz - W->terrainMinCorner[2]) * invChunkSize;
+	if (cx < 0.f || cz < 0.f || cx >= W->terrainChunksPerDim || cz >= W->terrainChunksPerDim) return -MI_FLT_MAX;
+	u32 chunk = (u32)cz * W->terrainChunksPerDim + (u32)cx;
+	if (!W->hTerrainValid[chunk]) return -MI_FLT_MAX;
+	cx = fmodf(cx, 1.f) * 128; cz = fmodf(cz, 1.f) * 128;
+	u32 x = (u32)cx, z = (u32)cz;
+	float relX = cx - x, relZ = cz - z;
+	const uint16_t* H = W->hTerrainHeights.data() + (size_t)chunk * 129 * 129;
+	float a = H[129 * z + x] * heightScale, b = H[129 * (z + 1) + x] * heightScale, c = H[129 * z + x + 1] * heightScale, d = H[129 * (z + 1) + x + 1] * heightScale;
+	float l0 = a + relX * (c - a), l1 = b + relX * (d - b);
+	return (l0 + relZ * (l1 - l0)) + W->terrainMinCorner[1];
+}
 
 // ---- cloth (cloth.h:5-60) ----
 uint32_t mi_add_cloth(mi_world* world, float width, float height, uint32_t gridSizeX, uint32_t gridSizeY, float totalMass, float stiffness, float damping, float gravityFactor)
@@ -1900,7 +1974,7 @@ int mi_debug_read_world_colliders(mi_world* world, void* outColliders64, float* 
 	}
 	return W->lastError;
 }
-uint32_t mi_debug_num_manifold_slots(mi_world* world) { CHECK_WORLD(0); W->refreshCounters(); return W->hCounters[CTR_NUM_PAIRS] ? W->hCounters[CTR_NUM_VALID] : 0; }
+uint32_t mi_debug_num_manifold_slots(mi_world* world) { CHECK_WORLD(0); W->refreshCounters(); return (W->hCounters[CTR_NUM_PAIRS] || W->terrainChunksPerDim) ? W->hCounters[CTR_NUM_VALID] : 0; }
 int mi_debug_read_manifolds(mi_world* world, uint32_t* outPairs2, uint32_t* outCounts, void* outContacts4x32, uint32_t* outBodyPairs2)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
@@ -1928,7 +2002,7 @@ int mi_debug_read_schedule(mi_world* world, uint32_t* outManifoldSlots, uint32_t
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	W->refreshCounters();
-	u32 n = W->hCounters[CTR_NUM_PAIRS] ? W->hCounters[CTR_NUM_MANIFOLDS] : 0;
+	u32 n = (W->hCounters[CTR_NUM_PAIRS] || W->terrainChunksPerDim) ? W->hCounters[CTR_NUM_MANIFOLDS] : 0;
 	std::vector<uint4> ids(n);
 	d2h(W, ids.data(), W->rowIds.p, sizeof(uint4) * n); // rowIds[s].w = manifold slot executed at schedule position s
 	for (u32 s = 0; s < n; ++s) outManifoldSlots[s] = ids[s].w;

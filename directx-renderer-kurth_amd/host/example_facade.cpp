@@ -53,6 +53,13 @@ int main()
 			.addComponent<trigger_component>([&](trigger_event e) { (e.type == trigger_event_enter ? enters : leaves)++; if (!(e.trigger == slab)) std::abort(); })
 			.addComponent<collider_component>(collider_component::asAABB(bounding_box::fromCenterRadius(vec3(0.f, 0.f, 0.f), vec3(3.f, 0.25f, 3.f)), mat));
 
+		{	// a flat terrain chunk well below the platform: exercises the heightmap entry points
+			scene.createEntity("terrain").addComponent<heightmap_collider_component>(1u, 64.f, mat);
+			std::vector<uint16_t> heights(129 * 129, 1000);
+			scene.heightmapSetHeights(0, 0, heights.data());
+			scene.heightmapUpdate(vec3(-32.f, -20.f, -32.f), 2.f);
+			if (!(scene.heightmapHeightAt(0.f, 0.f) < -19.9f)) std::abort();
+		}
 		auto banner = scene.createEntity("banner");
 		banner.addComponent<transform_component>(vec3(-8.f, 9.f, 0.f), quat()).addComponent<cloth_component>(4.f, 3.f, 12u, 9u, 2.f);
 

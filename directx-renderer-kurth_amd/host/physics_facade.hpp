@@ -81,6 +81,13 @@ namespace mi
 		cloth_component(float w, float h, uint32_t gx, uint32_t gy, float mass, float stiff = 0.5f, float damp = 0.3f, float gravity = 1.f)
 			: width(w), height(h), gridSizeX(gx), gridSizeY(gy), totalMass(mass), stiffness(stiff), damping(damp), gravityFactor(gravity) {}
 	};
+	// heightmap_collider_component(chunksPerDim, chunkSize, material), heightmap_collider.h:127-152: one per scene; update() and the chunks'
+	// setHeights() go through game_scene::heightmapUpdate / heightmapSetHeights once the component is added
+	struct heightmap_collider_component
+	{
+		uint32_t chunksPerDim; float chunkSize; physics_material material;
+		heightmap_collider_component(uint32_t c, float s, physics_material m) : chunksPerDim(c), chunkSize(s), material(m) {}
+	};
 	// trigger_event / trigger_component (physics.h:187-203)
 	enum trigger_event_type { trigger_event_enter, trigger_event_leave };
 	struct trigger_event;
@@ -224,6 +231,10 @@ namespace mi
 			uint32_t id = (e.field != 0xFFFFFFFFu) ? mi_add_force_field_collider(world, e.field, c.type, c.shape) : mi_add_trigger_collider(world, e.trigger, c.type, c.shape);
 			registerCollider(entityIndex, checkId(id, "zone collider"), c);
 		}
+		// heightmap_collider_component::update(minCorner, amplitudeScale) / collider(x, z).setHeights(heights) (heightmap_collider.h:131, 17)
+		void heightmapUpdate(vec3 minCorner, float amplitudeScale) { check(mi_heightmap_update(world, &minCorner.x, amplitudeScale), "heightmap update"); }
+		void heightmapSetHeights(uint32_t x, uint32_t z, const uint16_t* heights129x129) { check(mi_heightmap_set_chunk(world, x, z, heights129x129), "heightmap setHeights"); }
+		float heightmapHeightAt(float x, float z) const { return mi_heightmap_height_at(world, x, z); }
 		// drains the device's events and calls back in the reference's order (physics.cpp:1000-1032, 1128-1174)
 		void dispatchEvents(const physics_settings& settings)
 		{
@@ -276,6 +287,13 @@ namespace mi
 				mi_material m{ c.material.restitution, c.material.friction, c.material.density };
 				scene->registerCollider(index, scene->checkId(mi_add_collider(scene->world, e.body, c.type, c.shape, &m), "mi_add_collider"), c);
 			}
+		}
+		else if constexpr (std::is_same_v<T, heightmap_collider_component>)
+		{
+			heightmap_collider_component h(std::forward<Args>(args)...);
+			mi_material m{ h.material.restitution, h.material.friction, h.material.density };
+			const float origin[3] = { 0.f, 0.f, 0.f };
+			scene->check(mi_set_heightmap(scene->world, h.chunksPerDim, h.chunkSize, &m, origin, 1.f), "heightmap_collider_component");
 		}
 		else if constexpr (std::is_same_v<T, cloth_component>)
 		{

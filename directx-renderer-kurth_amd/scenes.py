@@ -56,6 +56,7 @@ class Scene:
         self.fields = []      # force fields: (force3, pos3 or None, rot4 or None, [(type, shape), ...]); no colliders = global
         self.triggers = []    # triggers: (pos3 or None, rot4 or None, [(type, shape), ...])
         self.collision_events = False
+        self.heightmap = None  # (chunksPerDim, chunkSize, material3, minCorner3, amplitudeScale, {(x, z): uint16[129, 129]})
         self.cloths = []      # (width, height, gridX, gridY, totalMass, stiffness, damping, gravityFactor, pos3, rot4): hung from its locked upper row at (pos, rot)
         self.cloth_iterations = (0, 1, 0)
         self.joint_edits = []  # (kind, index within kind, [(byte offset, "f4"|"u4", value), ...]): getConstraint(...).field = value after creation
@@ -121,6 +122,11 @@ class Scene:
                 world.add_trigger_collider(t, ctype, shape)
         if self.collision_events:
             world.enable_collision_events(True, True)
+        if self.heightmap is not None:
+            cpd, size, mat, corner, amplitude, chunks = self.heightmap
+            world.set_heightmap(cpd, size, mat, corner, amplitude)
+            for (x, z), h in sorted(chunks.items()):
+                world.heightmap_set_chunk(x, z, h)
         for width, height, gx, gy, mass, stiffness, damping, gravity, pos, rot in self.cloths:
             c = world.add_cloth(width, height, gx, gy, mass, stiffness, damping, gravity)
             world.cloth_set_fixed_vertices(c, pos, rot, True)
@@ -334,6 +340,51 @@ def _qrot(q, v):
     c = (-q[0], -q[1], -q[2], q[3])
     r = _qmul(_qmul(q, p), c)
     return (r[0], r[1], r[2])
+
+
+def terrain_heights(chunks_per_dim, seed=4242, roughness=1.0):
+    """Deterministic rolling terrain: a few sine waves + per-vertex hash noise, continuous across chunk borders, as uint16 heights per chunk."""
+    n = chunks_per_dim * 128 + 1
+    j, i = np.meshgrid(np.arange(n, dtype=np.float64), np.arange(n, dtype=np.float64))   # i = z row, j = x column
+    h = 0.5 + 0.22 * np.sin(j * 0.045 + 0.3) * np.cos(i * 0.037) + 0.12 * np.sin((i + j) * 0.11 + 1.0) + 0.05 * np.sin(i * 0.31) * np.sin(j * 0.29)
+    k = (i.astype(np.uint64) * np.uint64(73856093)) ^ (j.astype(np.uint64) * np.uint64(19349663)) ^ np.uint64(seed)
+    k = (k * np.uint64(2654435761)) % np.uint64(1 << 32)
+    h = h + roughness * 0.004 * (k.astype(np.float64) / float(1 << 32) - 0.5)
+    q = np.clip(np.round(h * 65535.0), 0, 65535).astype(np.uint16)
+    return {(x, z): q[z * 128:z * 128 + 129, x * 128:x * 128 + 129].copy() for z in range(chunks_per_dim) for x in range(chunks_per_dim)}
+
+
+def terrain(n=300, seed=31337, chunks_per_dim=2, chunk_size=24.0, amplitude=6.0):
+    """Spheres, capsules, AABB-born and OBB boxes (and a few cylinders / hulls, which the terrain ignores like the reference's) dropped on a
+    rolling heightmap of 2 x 2 chunks (one chunk left without heights: a hole), no ground plane: every supported collider type against
+    terrain triangles, body-body contacts on top."""
+    rng = XorShift64(seed)
+    s = Scene("terrain_%d" % n, dt=1.0 / 120.0)
+    span = chunks_per_dim * chunk_size
+    chunks = terrain_heights(chunks_per_dim)
+    if chunks_per_dim > 1:
+        del chunks[(chunks_per_dim - 1, chunks_per_dim - 1)]
+    s.heightmap = (chunks_per_dim, chunk_size, (0.1, 0.8, 1.0), (-span * 0.5, -2.0, -span * 0.5), amplitude, chunks)
+    oct_geo = s.add_hull_geometry(*hull_octahedron(0.6))
+    for i in range(n):
+        x, z = rng.between(-span * 0.42, span * 0.2), rng.between(-span * 0.42, span * 0.2)
+        y = rng.between(3.0, 9.0)
+        kind = i % 10
+        rot = rng.unit_quat() if kind != 4 else (0.0, 0.0, 0.0, 1.0)
+        b = s.add_body((x, y, z), rot, angular_damping=0.4 if kind != 4 else 1.0e6)
+        if kind in (0, 1, 2):
+            s.add_collider(b, SPHERE, (0.0, 0.0, 0.0, rng.between(0.3, 0.7)), DEFAULT_MATERIAL)
+        elif kind in (3, 5):
+            s.add_collider(b, CAPSULE, (0.0, -0.5, 0.0, 0.0, 0.5, 0.0, rng.between(0.2, 0.4)), DEFAULT_MATERIAL)
+        elif kind == 4:   # never rotates: stays an AABB in world space
+            s.add_collider(b, AABB, (-0.5, -0.4, -0.6, 0.5, 0.4, 0.6), DEFAULT_MATERIAL)
+        elif kind in (6, 7):
+            s.add_collider(b, OBB, (0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, rng.between(0.3, 0.8), rng.between(0.3, 0.8), rng.between(0.3, 0.8)), DEFAULT_MATERIAL)
+        elif kind == 8:
+            s.add_collider(b, CYLINDER, (0.0, -0.4, 0.0, 0.0, 0.4, 0.0, 0.4), DEFAULT_MATERIAL)
+        else:
+            s.add_collider(b, HULL, (0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, float(oct_geo)), DEFAULT_MATERIAL)
+    return s
 
 
 def cloths(n=3):
@@ -668,6 +719,8 @@ def by_name(name):
         return zones()
     if name == "cloths":
         return cloths()
+    if name == "terrain":
+        return terrain()
     if name == "vehicle":
         return vehicles(1)
     if name == "vehicles":

@@ -147,6 +147,17 @@ typedef struct mi_event { uint32_t kind, step, a, b, bodyA, bodyB; float positio
  * MI_ERR_CAPACITY (events were lost). */
 uint32_t mi_drain_events(mi_world* w, mi_event* out, uint32_t capacity);
 
+/* ---- heightmap terrain (row N4 of SURVEY §8f): heightmap_collider_component(chunksPerDim, chunkSize, material) + update(minCorner,
+ * amplitudeScale), heightmap_collider.h:127-152.  chunksPerDim x chunksPerDim chunks, each 129 x 129 uint16 heights (row-major, z rows)
+ * spanning chunkSize metres; height = minCorner.y + h / 65535 * amplitudeScale.  Every internal step, after the narrowphase, each
+ * sphere / capsule / AABB / OBB collider of a rigid body is collided with the triangles under it, plus one contact if its lowest point
+ * is below the surface (heightmap_collision.cpp:522-618; cylinders and hulls have no terrain case in the reference either).
+ * Terrain contacts raise no collision events (physics.cpp:1049). */
+int mi_set_heightmap(mi_world* w, uint32_t chunksPerDim, float chunkSize, const mi_material* material, const float minCorner[3], float amplitudeScale);
+int mi_heightmap_set_chunk(mi_world* w, uint32_t x, uint32_t z, const uint16_t* heights129x129); /* heightmap_collider_chunk::setHeights; chunks never set collide with nothing */
+int mi_heightmap_update(mi_world* w, const float minCorner[3], float amplitudeScale);
+float mi_heightmap_height_at(mi_world* w, float x, float z);   /* getHeightAt: -FLT_MAX outside the terrain */
+
 /* ---- cloth (row N4 of SURVEY §8f): cloth_component(width, height, gridSizeX, gridSizeY, totalMass, stiffness = .5, damping = .3,
  * gravityFactor = 1), cloth.h:8-9.  A grid of particles in the cloth's local frame (x across, -z down, upper row locked) with stretch /
  * shear / bend distance constraints; every internal step, after the rigid bodies, it receives the global force field as wind and runs

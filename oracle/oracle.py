@@ -65,8 +65,9 @@ def _lib(avx2=False):
                      "orc_add_slider_constraint_global", "orc_num_bodies", "orc_num_colliders", "orc_num_pairs", "orc_num_contacts",
                      "orc_num_collisions", "orc_sorting_axis_used", "orc_sorting_axis_next", "orc_num_contact_slots",
                      "orc_narrowphase_ordered", "orc_schedule", "orc_read_slot_counts", "orc_add_hull_geometry", "orc_test_physics_interaction",
-                     "orc_add_cloth", "orc_cloth_num_particles", "orc_cloth_num_constraints", "orc_add_force_field", "orc_add_trigger", "orc_add_force_field_collider", "orc_add_trigger_collider", "orc_drain_events"):
+                     "orc_terrain_slot_mismatch", "orc_terrain_contacts", "orc_add_cloth", "orc_cloth_num_particles", "orc_cloth_num_constraints", "orc_add_force_field", "orc_add_trigger", "orc_add_force_field_collider", "orc_add_trigger_collider", "orc_drain_events"):
             getattr(lib, name).restype = C.c_uint32
+        lib.orc_heightmap_height_at.restype = C.c_float
         _libs[key] = lib
     return _libs[key]
 
@@ -144,6 +145,30 @@ class OracleWorld:
         out = np.zeros(capacity, EVENT_DTYPE)
         n = self.lib.orc_drain_events(self.w, _p(out), C.c_uint32(capacity))
         return out[:n]
+
+    # ---- heightmap terrain (heightmap_collider.h:127-152) ----
+    def set_heightmap(self, chunks_per_dim, chunk_size, material, min_corner, amplitude_scale):
+        self.lib.orc_set_heightmap(self.w, C.c_uint32(chunks_per_dim), C.c_float(chunk_size), _f(material), _f(min_corner), C.c_float(amplitude_scale))
+
+    def heightmap_set_chunk(self, x, z, heights):
+        h = np.ascontiguousarray(heights, np.uint16).reshape(129, 129)
+        assert self.lib.orc_heightmap_set_chunk(self.w, C.c_uint32(x), C.c_uint32(z), _p(h)) == 0
+
+    def heightmap_update(self, min_corner, amplitude_scale):
+        self.lib.orc_heightmap_update(self.w, _f(min_corner), C.c_float(amplitude_scale))
+
+    def heightmap_height_at(self, x, z):
+        return float(self.lib.orc_heightmap_height_at(self.w, C.c_float(x), C.c_float(z)))
+
+    def terrain_contacts(self, collider, capacity=256):
+        """Terrain contacts of one collider at the poses of the last step, device emission order: rows {point3, depth, normal3, isLowestPoint}."""
+        out = np.zeros((capacity, 8), np.float32)
+        n = self.lib.orc_terrain_contacts(self.w, C.c_uint32(collider), _p(out), C.c_uint32(capacity))
+        return out[:min(n, capacity)]
+
+    def terrain_slot_mismatch(self):
+        """Follow mode: number of colliders whose terrain contact count differs from the slots the device reported (0 = same contact set)."""
+        return self.lib.orc_terrain_slot_mismatch(self.w)
 
     # ---- cloth (cloth.h:5-60; stepped after the rigid bodies, physics.cpp:1354-1358) ----
     def add_cloth(self, width, height, grid_x, grid_y, total_mass, stiffness=0.5, damping=0.3, gravity_factor=1.0):

@@ -8,8 +8,10 @@
 #include "oconstraints.h"
 #include "owide.h"
 #include "ocloth.h"
+#include "oheightmap.h"
 #include <vector>
 #include <cstdio>
+#include <map>
 
 namespace orc {
 
@@ -82,6 +84,8 @@ struct world
 	bool collisionBeginEvents = false, collisionEndEvents = false;  // physics_settings::collisionBeginCallback / collisionEndCallback set
 	std::vector<event_record> events;                               // callbacks in call order, drained by orc_drain_events
 	u32 stepIndex = 0;
+	u32 terrainSlotMismatch = 0;                                    // follow mode: colliders whose terrain contact count differs from the slots handed in
+	heightmap terrain; bool hasTerrain = false;                     // heightmap_collider_component (physics.cpp:1236-1249)
 	std::vector<cloth> cloths;                                      // cloth_component, stepped after the rigid bodies (physics.cpp:1354-1358)
 	u32 clothIterations[3] = { 0, 1, 0 };                           // physics_settings::numCloth{Velocity,Position,Drift}Iterations (physics.h:387-389)
 	bool clothColourOrder = false;                                  // Gauss-Seidel order of the cloth constraints: storage (reference) or colour (device)
@@ -442,19 +446,83 @@ static u32 packFrictionRestitution(const collider_union& A, const collider_union
 	return ((u32)(friction * 0xFFFF) << 16) | (u32)(restitution * 0xFFFF);
 }
 
+static u32 packTerrainFrictionRestitution(const collider_union& A, const heightmap& hm) // heightmap_collision.cpp:588-591
+{
+	float friction = clamp01(sqrtf(A.material.friction * hm.material.friction));
+	float restitution = clamp01(std::max(A.material.restitution, hm.material.restitution));
+	return ((u32)(friction * 0xFFFF) << 16) | (u32)(restitution * 0xFFFF);
+}
+static const u32 TERRAIN_SLOT = 0x80000000u; // follow mode: slot (collider, TERRAIN_SLOT | k) = the collider's k-th terrain contact in the device's emission order
+
+// heightmapCollision (heightmap_collision.cpp:522-618): every rigid-body collider against the terrain, contacts appended after the narrowphase's
+static void heightmapCollision(world& w)
+{
+	for (u32 i = 0; i < (u32)w.worldSpaceColliders.size(); ++i)
+	{
+		const collider_union& collider = w.worldSpaceColliders[i];
+		if (collider.objectType != physics_object_type_rigid_body) { continue; }
+		if (w.bodies[collider.objectIndex].removed) { continue; }
+		std::vector<terrain_contact> found;
+		heightmapContacts(w.terrain, collider, w.worldSpaceAABBs[i], found);
+		if (found.empty()) { continue; }
+		u32 fr = packTerrainFrictionRestitution(collider, w.terrain);
+		u32 collisionIndex = (u32)w.collidingPairs.size();
+		w.collidingPairs.push_back(collider_pair{ i, 0xFFFFFFFFu });
+		w.contactCountPerCollision.push_back((u8)std::min<size_t>(found.size(), 255));
+		for (const terrain_contact& t : found)
+		{
+			collision_contact c = t.contact; c.friction_restitution = fr;
+			w.contacts.push_back(c);
+			w.contactBodyPairs.push_back({ collider.objectIndex, (u32)w.bodies.size() });
+			w.contactCollisionIndex.push_back(collisionIndex);
+		}
+	}
+}
+// the device's emission order: chunk z, chunk x, cell z, cell x, triangle; the lowest-point contact last
+static void sortTerrainContactsDeviceOrder(std::vector<terrain_contact>& v)
+{
+	std::stable_sort(v.begin(), v.end(), [](const terrain_contact& l, const terrain_contact& r) { for (int i = 0; i < 5; ++i) if (l.key[i] != r.key[i]) return l.key[i] < r.key[i]; return false; });
+}
+
 static void narrowphaseOverride(world& w)
 {
 	const collider_union* cols = w.worldSpaceColliders.data();
 	w.contacts.clear(); w.contactBodyPairs.clear(); w.collidingPairs.clear(); w.contactCountPerCollision.clear(); w.contactCollisionIndex.clear();
 	w.slotCounts.assign(w.pairOverride.size(), 0);
 	std::vector<u32> slotStart(w.pairOverride.size(), 0);
+	std::map<u32, std::vector<terrain_contact>> terrainCache; std::map<u32, u32> terrainSeen;
 	for (size_t s = 0; s < w.pairOverride.size(); ++s)
 	{
 		collider_pair pair = w.pairOverride[s];
+		slotStart[s] = (u32)w.contacts.size();
+		if (pair.colliderB & TERRAIN_SLOT) // one terrain contact of collider A
+		{
+			if (!w.hasTerrain) { continue; }
+			auto it = terrainCache.find(pair.colliderA);
+			if (it == terrainCache.end())
+			{
+				std::vector<terrain_contact> found;
+				if (cols[pair.colliderA].objectType == physics_object_type_rigid_body) { heightmapContacts(w.terrain, cols[pair.colliderA], w.worldSpaceAABBs[pair.colliderA], found); }
+				sortTerrainContactsDeviceOrder(found);
+				it = terrainCache.emplace(pair.colliderA, std::move(found)).first;
+			}
+			u32 k = pair.colliderB & ~TERRAIN_SLOT;
+			terrainSeen[pair.colliderA]++;
+			if (k >= it->second.size()) { continue; }
+			const collider_union& A = cols[pair.colliderA];
+			collision_contact c = it->second[k].contact; c.friction_restitution = packTerrainFrictionRestitution(A, w.terrain);
+			u32 collisionIndex = (u32)w.collidingPairs.size();
+			w.collidingPairs.push_back(pair);
+			w.contactCountPerCollision.push_back(1);
+			w.slotCounts[s] = 1;
+			w.contacts.push_back(c);
+			w.contactBodyPairs.push_back({ A.objectIndex, (u32)w.bodies.size() });
+			w.contactCollisionIndex.push_back(collisionIndex);
+			continue;
+		}
 		const collider_union& A = cols[pair.colliderA];
 		const collider_union& B = cols[pair.colliderB];
 		contact_manifold contact; contact.numContacts = 0;
-		slotStart[s] = (u32)w.contacts.size();
 		if (intersectColliders(A, B, contact))
 		{
 			u32 fr = packFrictionRestitution(A, B);
@@ -470,6 +538,20 @@ static void narrowphaseOverride(world& w)
 				w.contactBodyPairs.push_back({ A.objectIndex, B.objectIndex });
 				w.contactCollisionIndex.push_back(collisionIndex);
 			}
+		}
+	}
+	// terrain contacts the device did not report: the oracle's own sweep over all colliders must find exactly the slots it was given
+	w.terrainSlotMismatch = 0;
+	if (w.hasTerrain)
+	{
+		for (u32 i = 0; i < (u32)w.worldSpaceColliders.size(); ++i)
+		{
+			if (cols[i].objectType != physics_object_type_rigid_body || w.bodies[cols[i].objectIndex].removed) { continue; }
+			std::vector<terrain_contact> found;
+			auto it = terrainCache.find(i);
+			if (it == terrainCache.end()) { heightmapContacts(w.terrain, cols[i], w.worldSpaceAABBs[i], found); }
+			size_t expected = (it == terrainCache.end()) ? found.size() : it->second.size();
+			if (expected != terrainSeen[i]) { w.terrainSlotMismatch++; }
 		}
 	}
 	w.customOrder.clear();
@@ -707,7 +789,11 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 	broadphase(w);
 	hullGeometryTable() = &w.hullGeometries;
 	if (w.usePairOverride) { narrowphaseOverride(w); }
-	else { narrowphasePairs(w, w.broadphasePairs.data(), (u32)w.broadphasePairs.size()); }
+	else
+	{
+		narrowphasePairs(w, w.broadphasePairs.data(), (u32)w.broadphasePairs.size());
+		if (w.hasTerrain) { heightmapCollision(w); }                               // :1236-1249
+	}
 
 	vec3 globalForce;
 	bool anyGlobalForce = globalForceField(w, globalForce);                        // :1253 (a world without global fields skips the += 0 of :1273)
@@ -947,6 +1033,39 @@ void orc_overlap_ordered(const void* colliders64, const u32* pairs2, u32 numPair
 	const collider_union* cols = (const collider_union*)colliders64;
 	for (u32 i = 0; i < numPairs; ++i) outOverlaps[i] = overlapColliders(cols[pairs2[2 * i]], cols[pairs2[2 * i + 1]]) ? 1 : 0;
 }
+// ---- heightmap terrain (heightmap_collider.h:127-152) ----
+void orc_set_heightmap(world* w, u32 chunksPerDim, float chunkSize, const float* material, const float* minCorner, float amplitudeScale)
+{
+	w->terrain.create(chunksPerDim, chunkSize, physics_material{ material[0], material[1], material[2] });
+	w->terrain.update(vec3(minCorner[0], minCorner[1], minCorner[2]), amplitudeScale);
+	w->hasTerrain = true;
+}
+int orc_heightmap_set_chunk(world* w, u32 x, u32 z, const u16* heights)
+{
+	if (!w->hasTerrain || x >= w->terrain.chunksPerDim || z >= w->terrain.chunksPerDim) return 1;
+	w->terrain.chunks[z * w->terrain.chunksPerDim + x].setHeights(heights);
+	return 0;
+}
+void orc_heightmap_update(world* w, const float* minCorner, float amplitudeScale) { w->terrain.update(vec3(minCorner[0], minCorner[1], minCorner[2]), amplitudeScale); }
+float orc_heightmap_height_at(world* w, float x, float z) { return w->hasTerrain ? w->terrain.getHeightAt(x, z) : -FLT_MAX; }
+u32 orc_terrain_slot_mismatch(world* w) { return w->terrainSlotMismatch; }
+// terrain contacts of one collider at the poses of the last step, in the device's emission order: {point3, depth, normal3, key0} per contact
+u32 orc_terrain_contacts(world* w, u32 colliderIndex, float* out8, u32 capacity)
+{
+	if (!w->hasTerrain || colliderIndex >= w->worldSpaceColliders.size()) return 0;
+	std::vector<terrain_contact> found;
+	heightmapContacts(w->terrain, w->worldSpaceColliders[colliderIndex], w->worldSpaceAABBs[colliderIndex], found);
+	sortTerrainContactsDeviceOrder(found);
+	u32 n = std::min<u32>((u32)found.size(), capacity);
+	for (u32 i = 0; i < n; ++i)
+	{
+		const collision_contact& c = found[i].contact;
+		float* o = out8 + 8 * i;
+		o[0] = c.point.x; o[1] = c.point.y; o[2] = c.point.z; o[3] = c.penetrationDepth; o[4] = c.normal.x; o[5] = c.normal.y; o[6] = c.normal.z; o[7] = (found[i].key[0] == ~0u) ? 1.f : 0.f;
+	}
+	return (u32)found.size();
+}
+
 // ---- cloth (cloth.h:5-60) ----
 u32 orc_add_cloth(world* w, float width, float height, u32 gridSizeX, u32 gridSizeY, float totalMass, float stiffness, float damping, float gravityFactor)
 {

@@ -58,6 +58,9 @@ def test_facade_matches_ctypes_world(tmp_path, mi):
     trig = w.add_trigger(pos=(0, 3, 0), rot=(0, 0, 0, 1))
     w.add_trigger_collider(trig, mi.AABB, [-3, -0.25, -3, 3, 0.25, 3])
     w.enable_collision_events()
+    w.set_heightmap(1, 64.0, mat, (0, 0, 0), 1.0)
+    w.heightmap_set_chunk(0, 0, np.full((129, 129), 1000, np.uint16))
+    w.heightmap_update((-32, -20, -32), 2.0)
     banner = w.add_cloth(4.0, 3.0, 12, 9, 2.0)
     w.cloth_set_fixed_vertices(banner, (-8, 9, 0), (0, 0, 0, 1), True)
     for _ in range(120):
