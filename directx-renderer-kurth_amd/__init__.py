@@ -68,7 +68,7 @@ EXPORTED_SYMBOLS = [
     "mi_add_distance_constraint_local", "mi_add_distance_constraint_global", "mi_add_ball_constraint_local", "mi_add_ball_constraint_global",
     "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
     "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_delete_all_constraints_from_body", "mi_delete_body",
-    "mi_add_force_field", "mi_set_force_field", "mi_add_trigger", "mi_add_force_field_collider", "mi_add_trigger_collider", "mi_enable_collision_events", "mi_drain_events",
+    "mi_add_force_field", "mi_set_force_field", "mi_add_trigger", "mi_add_force_field_collider", "mi_add_trigger_collider", "mi_set_force_field_transform", "mi_set_trigger_transform", "mi_enable_collision_events", "mi_drain_events",
     "mi_set_heightmap", "mi_heightmap_set_chunk", "mi_heightmap_update", "mi_heightmap_height_at",
     "mi_add_cloth", "mi_cloth_set_fixed_vertices", "mi_cloth_set_properties", "mi_set_cloth_iterations", "mi_num_cloths", "mi_cloth_num_particles", "mi_cloth_read",
     "mi_test_physics_interaction", "mi_apply_force_torque", "mi_set_velocity",
@@ -224,6 +224,12 @@ class World:
     def add_trigger_collider(self, trigger, ctype, shape):
         s = np.zeros(10, np.float32); s[:len(shape)] = shape
         return self._id(self.lib.mi_add_trigger_collider(self.w, C.c_uint32(trigger), C.c_uint32(ctype), _f(s)))
+
+    def set_force_field_transform(self, field, pos, rot=(0, 0, 0, 1)):
+        self._check(self.lib.mi_set_force_field_transform(self.w, C.c_uint32(field), _f(pos), _f(rot)))
+
+    def set_trigger_transform(self, trigger, pos, rot=(0, 0, 0, 1)):
+        self._check(self.lib.mi_set_trigger_transform(self.w, C.c_uint32(trigger), _f(pos), _f(rot)))
 
     def enable_collision_events(self, begin=True, end=True):
         """physics_settings::collisionBeginCallback / collisionEndCallback set; enable before the first step."""

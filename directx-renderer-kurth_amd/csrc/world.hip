@@ -1222,6 +1222,37 @@ uint32_t mi_add_trigger_collider(mi_world* world, uint32_t trigger, uint32_t typ
 	if (id != 0xFFFFFFFFu) t.numColliders++;
 	return id;
 }
+static int moveZone(World* w, u32 zoneType, u32 zoneIndex, float* zpos, float* zrot, const float* pos, const float* rot)
+{
+	if (!pos || !rot) { w->fail(MI_ERR_INVALID_ARGUMENT, "zone transform: pos / rot is NULL"); return w->lastError; }
+	memcpy(zpos, pos, 12); memcpy(zrot, rot, 16);
+	for (u32 i = 0; i < (u32)w->colliders.size(); ++i)
+	{
+		World::HCollider& c = w->colliders[i];
+		if (c.zoneType != zoneType || c.zoneIndex != zoneIndex) continue;
+		memcpy(c.spos, pos, 12); memcpy(c.srot, rot, 16);
+		if (!w->topologyDirty && i < w->nc) // the collider is on the device already: patch its static pose in place
+		{
+			float4 sp[2] = { make_float4(pos[0], pos[1], pos[2], 0.f), make_float4(rot[0], rot[1], rot[2], rot[3]) };
+			MI_CHECK(hipMemcpyAsync(w->colStaticPose.p + 2 * (size_t)i, sp, sizeof(sp), hipMemcpyHostToDevice, w->stream));
+			MI_CHECK(hipStreamSynchronize(w->stream));
+		}
+	}
+	return w->lastError;
+}
+int mi_set_force_field_transform(mi_world* world, uint32_t field, const float pos[3], const float rot[4])
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (field >= W->fields.size()) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_set_force_field_transform: field out of range"); return W->lastError; }
+	W->fields[field].hasTransform = 1u; W->fieldsDirty = true;
+	return moveZone(W, 2u, field, W->fields[field].pos, W->fields[field].rot, pos, rot);
+}
+int mi_set_trigger_transform(mi_world* world, uint32_t trigger, const float pos[3], const float rot[4])
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (trigger >= W->triggers.size()) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_set_trigger_transform: trigger out of range"); return W->lastError; }
+	return moveZone(W, 3u, trigger, W->triggers[trigger].pos, W->triggers[trigger].rot, pos, rot);
+}
 int mi_enable_collision_events(mi_world* world, int begin, int end)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);

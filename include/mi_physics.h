@@ -132,6 +132,10 @@ uint32_t mi_add_trigger(mi_world* w, const float pos[3], const float rot[4]);
  * mi_add_collider, in the entity's local space; no material.  Return the collider id. */
 uint32_t mi_add_force_field_collider(mi_world* w, uint32_t field, uint32_t type, const float* shape);
 uint32_t mi_add_trigger_collider(mi_world* w, uint32_t trigger, uint32_t type, const float* shape);
+/* Moving a force-field / trigger entity (writing its transform_component): its colliders follow, a field's force is rotated by the new
+ * rotation.  Takes effect at the next step. */
+int mi_set_force_field_transform(mi_world* w, uint32_t field, const float pos[3], const float rot[4]);
+int mi_set_trigger_transform(mi_world* w, uint32_t trigger, const float pos[3], const float rot[4]);
 /* physics_settings::collisionBeginCallback / collisionEndCallback (physics.h:394-395) set or not.  Enable before the first step:
  * the previous step's collision set is only kept while one of the two is on. */
 int mi_enable_collision_events(mi_world* w, int begin, int end);

@@ -132,6 +132,12 @@ class OracleWorld:
         s = np.zeros(10, np.float32); s[:len(shape)] = shape
         return self.lib.orc_add_trigger_collider(self.w, C.c_uint32(trigger), C.c_uint32(ctype), _f(s))
 
+    def set_force_field_transform(self, field, pos, rot=(0, 0, 0, 1)):
+        assert self.lib.orc_set_force_field_transform(self.w, C.c_uint32(field), _f(pos), _f(rot)) == 0
+
+    def set_trigger_transform(self, trigger, pos, rot=(0, 0, 0, 1)):
+        assert self.lib.orc_set_trigger_transform(self.w, C.c_uint32(trigger), _f(pos), _f(rot)) == 0
+
     def enable_collision_events(self, begin=True, end=True):
         self.lib.orc_enable_collision_events(self.w, int(begin), int(end))
 

@@ -1105,6 +1105,21 @@ void orc_cloth_read_constraints(world* w, u32 c, void* out16, u32* outColour) //
 	memcpy(out16, cl.constraints.data(), sizeof(cloth_constraint) * cl.constraints.size());
 	memcpy(outColour, cl.colour.data(), sizeof(u32) * cl.colour.size());
 }
+static void moveZoneColliders(world* w, u32 zoneType, u32 zoneIndex, const trs& t) { for (collider& c : w->colliders) if (c.zoneType == zoneType && c.zoneIndex == zoneIndex && c.parent == STATIC_BODY) c.staticTransform = t; }
+int orc_set_force_field_transform(world* w, u32 field, const float* pos, const float* rot)
+{
+	if (field >= w->forceFields.size()) return 1;
+	w->forceFields[field].hasTransform = true; w->forceFields[field].transform = makeTrs(pos, rot);
+	moveZoneColliders(w, physics_object_type_force_field, field, w->forceFields[field].transform);
+	return 0;
+}
+int orc_set_trigger_transform(world* w, u32 trig, const float* pos, const float* rot)
+{
+	if (trig >= w->triggers.size()) return 1;
+	w->triggers[trig].transform = makeTrs(pos, rot);
+	moveZoneColliders(w, physics_object_type_trigger, trig, w->triggers[trig].transform);
+	return 0;
+}
 void orc_enable_collision_events(world* w, int begin, int end) { w->collisionBeginEvents = begin != 0; w->collisionEndEvents = end != 0; }
 u32 orc_drain_events(world* w, void* out60, u32 capacity)
 {
