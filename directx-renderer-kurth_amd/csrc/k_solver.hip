@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(256, BLOCKS_PER_CU) k_solve_flow(u32* counters
 					probes += flowTrip(m, it, itBegin, itEnd, epoch, rsrc, rowCap, rowPlanes, rowLambda, vel, status, hopTicks, backoffCap, notBefore, readyNow, eager);
 					period = readyPrev ? (u32)(readyNow - readyPrev) : 0u;
 					readyPrev = readyNow;
-					if (trace) trace[(size_t)slot * 32 + (it & 31u)] = wall_clock64(); // developer timeline: when this manifold finished iteration it
+					if (trace) { trace[(size_t)slot * 32 + (it & 31u)] = readyNow; if (it == itBegin + 10u) trace[(size_t)slot * 32 + 31u] = notBefore; } // developer timeline: when this manifold saw its inputs complete in iteration it (per lane: the wave reconverges later); for iteration 10 also until when it slept
 				}
 				rowLambda[slot] = m.r0.lam;
 			}
