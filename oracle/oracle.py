@@ -45,9 +45,16 @@ class Settings(C.Structure):
 
 
 def build(force=False):
-    """Compile the oracle with its committed Makefile (gcc only)."""
-    if force or not (os.path.exists(os.path.join(_HERE, "liboracle.so")) and os.path.exists(os.path.join(_HERE, "liboracle_avx2.so"))):
-        subprocess.check_call(["make", "-C", _HERE, "-j2"], stdout=subprocess.DEVNULL)
+    """Compile the oracle with its committed Makefile (gcc only).  make is a no-op when the libraries are newer than their sources; on a
+    box without the sources' build tools the prebuilt libraries are used as they are."""
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "clean"], stdout=subprocess.DEVNULL)
+    have = os.path.exists(os.path.join(_HERE, "liboracle.so")) and os.path.exists(os.path.join(_HERE, "liboracle_avx2.so"))
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-j2"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL if have else None)
+    except (OSError, subprocess.CalledProcessError):
+        if not have:
+            raise
 
 
 _libs = {}
