@@ -1203,10 +1203,21 @@ void launch_narrowphase(World& w, u32 numPairs)
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gjk<1>), grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_CLOSED>), grid, block, 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p);
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_narrow<GROUP_BOX>), dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p);
-	u32 epaBlocks = std::min<u32>((numPairs + EPA_WAVES_PER_BLOCK - 1) / EPA_WAVES_PER_BLOCK, 256u * 4u); // 4 blocks of 4 waves (38.5 KB of LDS each) fit a CU
+	// The waves stride over the hit list: launch exactly as many workgroups as are resident at once (registers allow 3 per CU, the 38.5 KB
+	// of LDS would allow 4), or the last quarter of a 4-per-CU grid runs as a second, mostly empty round.
+	static int epaPerCU[2] = { 0, 0 }; static int numCUs = 0;
+	if (!numCUs)
+	{
+		hipDeviceProp_t prop; MI_CHECK(hipGetDeviceProperties(&prop, w.device)); numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+		MI_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&epaPerCU[0], k_epa<0>, 64 * EPA_WAVES_PER_BLOCK, 0));
+		MI_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&epaPerCU[1], k_epa<1>, 64 * EPA_WAVES_PER_BLOCK, 0));
+		if (const char* e = getenv("MI_EPA_BLOCKS_PER_CU")) epaPerCU[0] = epaPerCU[1] = std::max(1, atoi(e));
+		for (int& v : epaPerCU) if (v < 1) v = 3;
+	}
+	u32 epaBlocks = std::min<u32>((numPairs + EPA_WAVES_PER_BLOCK - 1) / EPA_WAVES_PER_BLOCK, (u32)(numCUs * epaPerCU[0]));
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epa<0>), dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
 	if (!w.hulls.empty())
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epa<1>), dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epa<1>), dim3(std::min<u32>((numPairs + EPA_WAVES_PER_BLOCK - 1) / EPA_WAVES_PER_BLOCK, (u32)(numCUs * epaPerCU[1]))), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
 	if (!w.fields.empty() || !w.triggers.empty())
 	{
 		PairSetView tv = { w.triggers.empty() ? nullptr : w.triggerSet[w.triggerCur].p, w.triggers.empty() ? nullptr : w.triggerSet[w.triggerCur ^ 1].p, w.triggerSetSize - 1, 64u - (u32)__builtin_ctz(w.triggerSetSize ? w.triggerSetSize : 2u) };
