@@ -158,16 +158,19 @@ void launch_build_colliders(World& w)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, const float4* __restrict__ pose, const float4* __restrict__ bprops,
 	const float4* __restrict__ force, const uint8_t* __restrict__ simMask, float4* __restrict__ vel, float4* __restrict__ cog, float4* __restrict__ invIw,
-	u64* __restrict__ bodyMask, u64* __restrict__ claim)
+	u64* __restrict__ bodyMask, u64* __restrict__ claim, float4* __restrict__ velBackup)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > nb) return;
 	if (bodyMask) { bodyMask[i] = 0ull; claim[i] = ~0ull; claim[(size_t)nb + i] = ~0ull; } // per-body state of the colouring that follows (saves three fill launches)
-	if (i < nb && !simMask[i]) return;
+	// velBackup: the pre-solve velocities, kept in case the dataflow sweep has to be redone (World::recoverFlow); written here, where
+	// every body's velocity passes through registers anyway, instead of by a copy of the whole array afterwards
+	if (i < nb && !simMask[i]) { if (velBackup) { velBackup[2 * i] = vel[2 * i]; velBackup[2 * i + 1] = vel[2 * i + 1]; } return; }
 	if (i == nb) // static dummy (physics.cpp:1279)
 	{
 		float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 		vel[2 * i] = z; vel[2 * i + 1] = z; cog[i] = z; invIw[3 * i] = z; invIw[3 * i + 1] = z; invIw[3 * i + 2] = z;
+		if (velBackup) { velBackup[2 * i] = z; velBackup[2 * i + 1] = z; }
 		return;
 	}
 	V3 pos = v3f4(pose[2 * i]);
@@ -194,6 +197,7 @@ __global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, cons
 
 	vel[2 * i] = make_float4(v.x, v.y, v.z, invMass);
 	vel[2 * i + 1] = make_float4(wv.x, wv.y, wv.z, 0.f);
+	if (velBackup) { velBackup[2 * i] = make_float4(v.x, v.y, v.z, invMass); velBackup[2 * i + 1] = make_float4(wv.x, wv.y, wv.z, 0.f); }
 	cog[i] = make_float4(gpos.x, gpos.y, gpos.z, invMass);
 	invIw[3 * i] = make_float4(Iw.m00, Iw.m10, Iw.m20, 0.f);
 	invIw[3 * i + 1] = make_float4(Iw.m01, Iw.m11, Iw.m21, 0.f);
@@ -203,7 +207,7 @@ __global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, cons
 void launch_integrate_forces(World& w, float dt)
 {
 	hipLaunchKernelGGL(k_integrate_forces, dim3((w.nb + 1 + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.force.p,
-		w.simMask.p, w.vel.p, w.cog.p, w.invIw.p, flow_num_regions(w) > 1 ? nullptr : w.bodyMask.p, w.claim.p);
+		w.simMask.p, w.vel.p, w.cog.p, w.invIw.p, flow_num_regions(w) > 1 ? nullptr : w.bodyMask.p, w.claim.p, w.useFlow ? w.velBackup.p : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -645,6 +645,7 @@ int World::stepInternal(float dt, u32 iters)
 
 	flow_choose_regions(*this);
 	launch_apply_fields(*this);                            // :963-967, :1273
+	if (useFlow) velBackup.ensure(2 * ((size_t)nb + 1), stream);
 	launch_integrate_forces(*this, dt);
 	launch_collision_events(*this, numPairs);              // :1284 (handleCollisionCallbacks: after the force integration)
 	launch_coloring(*this, numPairs);
@@ -663,9 +664,7 @@ int World::stepInternal(float dt, u32 iters)
 	{
 		u32 est = std::min<u32>(numPairs, lastNumManifolds + lastNumManifolds / 32 + 512);
 		if (T) MI_CHECK(hipEventRecord(ev[3], stream));
-		velBackup.ensure(2 * ((size_t)nb + 1), stream);
-		MI_CHECK(hipMemcpyAsync(velBackup.p, vel.p, sizeof(float4) * 2 * ((size_t)nb + 1), hipMemcpyDeviceToDevice, stream));
-		pendingDt = dt; pendingIters = iters; flowPending = true;
+		pendingDt = dt; pendingIters = iters; flowPending = true; // (the pre-solve velocities are in velBackup: k_integrate_forces)
 		u32 numJointKernels = 0;
 		for (auto& js : joints) numJointKernels += js.colorStart.empty() ? 0 : (u32)js.colorStart.size() - 1;
 		hCounters[CTR_KEY_START] = 0; // launch_solve_flow subtracts the first slot of its first colour: colour 0 starts at slot 0
@@ -687,8 +686,6 @@ int World::stepInternal(float dt, u32 iters)
 	bool flowStep = !noSync2 && useFlow && !flowCooldown && numPairs && numColors;
 	if (flowStep) // pre-solve velocities, in case the dataflow sweep has to be redone (World::recoverFlow)
 	{
-		velBackup.ensure(2 * ((size_t)nb + 1), stream);
-		MI_CHECK(hipMemcpyAsync(velBackup.p, vel.p, sizeof(float4) * 2 * ((size_t)nb + 1), hipMemcpyDeviceToDevice, stream));
 		pendingDt = dt; pendingIters = iters; flowPending = true;
 	}
 	if (!noSync2)
