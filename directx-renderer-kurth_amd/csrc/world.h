@@ -104,10 +104,10 @@ struct World
 	struct HTrigger { float pos[3], rot[4]; u32 numColliders; };                                 // trigger_component (physics.h:200-203); the callback becomes mi_drain_events
 	std::vector<HField> fields; std::vector<HTrigger> triggers;
 	// heightmap_collider_component (heightmap_collider.h:127-152): chunksPerDim x chunksPerDim chunks of 129 x 129 uint16 heights
-	u32 terrainChunksPerDim = 0, terrainSlotsPerCollider = 8; float terrainChunkSize = 0.f, terrainAmplitude = 1.f, terrainMinCorner[3] = { 0.f, 0.f, 0.f }, terrainMaterial[3] = { 0.f, 0.f, 0.f };
+	u32 terrainChunksPerDim = 0, terrainSlotsPerCollider = 8, terrainMinSlots = 8192; float terrainChunkSize = 0.f, terrainAmplitude = 1.f, terrainMinCorner[3] = { 0.f, 0.f, 0.f }, terrainMaterial[3] = { 0.f, 0.f, 0.f };
 	std::vector<uint16_t> hTerrainHeights; std::vector<u32> hTerrainValid;
 	DevBuf<uint16_t> terrainHeights; DevBuf<u32> terrainValid, terrainCounts, terrainOffsets;
-	u32 terrainSlotCap() const { return terrainChunksPerDim ? std::max(8192u, terrainSlotsPerCollider * (u32)colliders.size()) : 0u; }
+	u32 terrainSlotCap() const { return terrainChunksPerDim ? std::max(terrainMinSlots, terrainSlotsPerCollider * (u32)colliders.size()) : 0u; }
 	u32 prevTruePairs = 0;                // broadphase overlaps of the last step (prevNumPairs counts the terrain slots too)
 	// cloth_component (cloth.h:5-60): parameters + host mirror of the particle state (authoritative until the first step; refreshed by downloadCloths)
 	struct HClothConstraint { u32 a, b; float restDistance, inverseMassSum; u32 color; };

@@ -1306,6 +1306,7 @@ int mi_set_heightmap(mi_world* world, uint32_t chunksPerDim, float chunkSize, co
 	W->terrainHeights.ensure(W->hTerrainHeights.size(), W->stream); W->terrainValid.ensure(chunks, W->stream);
 	MI_CHECK(hipMemsetAsync(W->terrainValid.p, 0, sizeof(u32) * chunks, W->stream));
 	if (const char* e = getenv("MI_TERRAIN_SLOTS_PER_COLLIDER")) W->terrainSlotsPerCollider = (u32)std::max(1, atoi(e));
+	if (const char* e = getenv("MI_TERRAIN_MIN_SLOTS")) W->terrainMinSlots = (u32)std::max(1, atoi(e));
 	return W->lastError;
 }
 int mi_heightmap_set_chunk(mi_world* world, uint32_t x, uint32_t z, const uint16_t* heights129x129) // heightmap_collider_chunk::setHeights

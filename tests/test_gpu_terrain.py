@@ -1,5 +1,7 @@
 """Heightmap terrain collision (row N4 of SURVEY §8f; reference heightmap_collider.h / heightmap_collision.cpp, physics.cpp:1236-1249) on the
 GPU against the oracle in follow mode."""
+import os
+
 import numpy as np
 import pytest
 
@@ -73,3 +75,22 @@ def test_terrain_travels_with_the_snapshot(mi):
         g.step_internal(scene.dt, 30); r.step_internal(scene.dt, 30)
     assert np.array_equal(g.transforms(1), r.transforms(1)) and np.array_equal(g.velocities(), r.velocities())
     assert g.heightmap_height_at(-3.0, -5.0) == r.heightmap_height_at(-3.0, -5.0) > -1e30
+
+
+def test_terrain_slot_budget_overflow_is_reported(mi):
+    """More terrain contacts than the slot budget allows: contacts would be dropped, so the world fails with MI_ERR_CAPACITY at its next
+    synchronisation instead of simulating on without them."""
+    from directx_renderer_kurth_amd import scenes
+    os.environ["MI_TERRAIN_SLOTS_PER_COLLIDER"] = "1"; os.environ["MI_TERRAIN_MIN_SLOTS"] = "2"
+    try:
+        s = scenes.Scene("terrain_overflow", dt=1.0 / 120.0)
+        s.heightmap = (1, 32.0, (0.1, 0.8, 1.0), (-16.0, 0.0, -16.0), 4.0, scenes.terrain_heights(1))
+        for k in range(4):
+            b = s.add_body((2.0 * k - 3.0, 3.2, 0.5 * k))
+            s.add_collider(b, scenes.OBB, (0, 0, 0, 1, 0, 0, 0, 0.9, 0.3, 0.9), scenes.DEFAULT_MATERIAL)
+        g = s.instantiate(mi.World())
+        with pytest.raises(mi.PhysicsError):
+            for _ in range(240):
+                g.step_internal(s.dt, 30)
+    finally:
+        del os.environ["MI_TERRAIN_SLOTS_PER_COLLIDER"]; del os.environ["MI_TERRAIN_MIN_SLOTS"]
