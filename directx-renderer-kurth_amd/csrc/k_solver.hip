@@ -978,7 +978,7 @@ void launch_solve_flow(World& w, u32 numManifolds, u32 itBegin, u32 itEnd, u32 f
 	u32 blocks = (regions > 1) ? flowMaxBlocks(w, variant) : std::min<u32>(need, flowMaxBlocks(w, variant));
 	auto kernel = variant == 0 ? k_solve_flow<3> : k_solve_flow<2>;
 	hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, w.stream, w.dCounters.p, w.nb, w.rowCap, w.rowPlanes.p, w.rowShared.p, w.rowLambda.p, w.rowIds.p,
-		w.mKeySorted.p, w.bodyMask.p, w.vel.p, w.flow.p, (u32)(words * sizeof(u64)), w.flowEpoch << 12, itBegin, itEnd, w.flowHopTicks, w.flowBackoffCap, w.flowPredictFrac,
+		w.mKeySorted.p, w.bodyMask.p, w.vel.p, w.flow.p, (u32)(words * sizeof(u64)), w.flowEpoch << 12, itBegin, itEnd, numManifolds <= w.flowEagerMax ? w.flowHopTicks : w.flowHopTicksLarge, w.flowBackoffCap, w.flowPredictFrac,
 		regions, w.flowOrder.p, w.regMask.p, w.flowTrace.p, firstColor, numManifolds <= w.flowEagerMax ? 1u : 0u);
 }
 

@@ -170,6 +170,7 @@ struct World
 	DevBuf<float4> velBackup; bool flowPending = false; float pendingDt = 0.f; u32 pendingIters = 0, flowCooldown = 0, flowTestAbortStep = ~0u;
 	void recoverFlow(); int resolvePendingFlow();
 	u32 flowHopTicks = 100, flowBackoffCap = 64, flowPredictFrac = 192; // poll pacing: 10 ns ticks; fraction (/256) of the iteration period slept through (MI_FLOW_HOP / _CAP / _PREDICT)
+	u32 flowHopTicksLarge = 220;          // assumed hand-over time above flowEagerMax manifolds: measured 2.2 us there, ~1 us in small worlds (MI_FLOW_HOP_LARGE)
 	// force fields, triggers, events
 	DevBuf<float4> fieldForce;            // per field: world-space force (localized fields only; global ones are summed on the host into globalForce)
 	DevBuf<u32> fieldMask; u32 fieldWords = 0; // per body: bit f set = inside localized field f this step (set by k_zone_overlap, consumed + cleared by k_apply_fields)

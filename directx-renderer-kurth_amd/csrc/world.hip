@@ -56,7 +56,8 @@ World::World(int dev) : device(dev)
 	if (const char* e = getenv("MI_FLOW_MAX")) flowMaxManifolds = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_EAGER")) flowEagerMax = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_TEST_ABORT")) flowTestAbortStep = (u32)atoi(e); // tests: make the dataflow sweep of that internal step give up
-	if (const char* e = getenv("MI_FLOW_HOP")) flowHopTicks = (u32)atoi(e);
+	if (const char* e = getenv("MI_FLOW_HOP")) flowHopTicks = flowHopTicksLarge = (u32)atoi(e);
+	if (const char* e = getenv("MI_FLOW_HOP_LARGE")) flowHopTicksLarge = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_CAP")) flowBackoffCap = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_PREDICT")) flowPredictFrac = (u32)atoi(e);
 }
