@@ -1920,6 +1920,15 @@ int mi_get_stats(mi_world* world, mi_stats* out)
 	W->refreshCounters();     // counts of the last step (one small read-back if the step did not do it itself)
 	W->harvestTiming();
 	mi_stats& st = W->stats;
+	if (W->useFlow && W->stats.numInternalSteps && W->dCounters.p)
+	{
+		// a step that read its counters back before the solve (the launch-per-round colouring path) has not seen its own poll count yet
+		u32 probes = 0;
+		W->resolvePendingFlow();
+		MI_CHECK(hipMemcpyAsync(&probes, W->dCounters.p + CTR_FLOW_PROBES, sizeof(u32), hipMemcpyDeviceToHost, W->stream));
+		MI_CHECK(hipStreamSynchronize(W->stream));
+		st.flowProbes = probes;
+	}
 	if (W->accTimed)
 	{
 		double n = W->accTimed;
