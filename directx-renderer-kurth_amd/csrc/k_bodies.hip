@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, cons
 void launch_integrate_forces(World& w, float dt)
 {
 	hipLaunchKernelGGL(k_integrate_forces, dim3((w.nb + 1 + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.force.p,
-		w.simMask.p, w.vel.p, w.cog.p, w.invIw.p, flow_num_regions(w) > 1 ? nullptr : w.bodyMask.p, w.claim.p, w.useFlow ? w.velBackup.p : nullptr);
+		w.simMask.p, w.vel.p, w.cog.p, w.invIw.p, w.bodyMask.p, w.claim.p, w.backupVelocities ? w.velBackup.p : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

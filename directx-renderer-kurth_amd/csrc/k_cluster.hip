@@ -1,0 +1,827 @@
+// Contact sweep around LDS-resident clusters ("K11-cluster"): the production contact solver.
+//
+// Why.  A Gauss-Seidel sweep over a proper colouring has (colours x iterations) ~ 20 x 30 = 600 dependent phases per step.  Across the
+// chip a phase boundary costs a launch (~5 us) or a tagged hand-over through L2 / the fabric (~2 us); inside ONE workgroup it
+// costs a barrier over LDS (~0.3 us).  So the world is cut into spatial clusters that one 1024-lane workgroup each solves
+// entirely out of LDS for all iterations, and only what a cut crosses goes through memory:
+//
+//   phase 0..P-1 ("partitions"): the bodies are ordered along a Morton curve (each phase its own, shifted, curve) and the curve is
+//       chunked by weight into tasks of <= ~960 manifolds; a manifold whose two bodies fall into the same chunk is INTERIOR to
+//       that task.  Phase p only looks at what phases < p left over, so its chunks cover ever larger volumes and swallow the
+//       earlier phases' cut surfaces.
+//   phase P ("rest"): whatever is cut in every partition (a few hundred manifolds at 200k) forms one last task.
+//
+// Tasks of one phase share no body, so they run concurrently, one workgroup each; a workgroup runs its (at most one per phase)
+// tasks in phase order, iteration after iteration.  Inside a task the manifolds are coloured locally (in LDS, by the task's
+// workgroup: k_cl_color) and swept colour by colour with a workgroup barrier in between; body velocities live in LDS for the whole
+// launch, the first contact row of the first task's manifolds in registers, all other rows in LDS (global memory only when the
+// LDS budget is exceeded).  A body touched in more than one phase is handed from task to task through the tagged 2 x 16-byte
+// records of the old dataflow sweep (sc1 store / sc1 poll, MI355X_MICROARCH.md "tagged granules"): with d = number of phases that
+// touch the body, the task of phase p is its r-th user, r = popcount(phaseMask & ((1 << p) - 1)), waits for turn
+// epoch + it * d + r and publishes + 1.  Every wait points to a strictly earlier (iteration, phase): no cycles.
+//
+// The result is a Gauss-Seidel sweep in the sequential order (phase, task, local colour, position) — the order
+// mi_debug_read_schedule reports and the CPU oracle follows — with bit-identical arithmetic to the launch-per-colour sweep.
+#include "world.h"
+#include "solver_rows.h"
+
+void prim_sort_pairs_u32(World& w, const u32* kin, u32* kout, const u32* vin, u32* vout, u32 n, u32 bits);
+void prim_exclusive_scan_u32(World& w, const u32* in, u32* out, u32 n);
+
+#define CL_LANES 1024u                    // k_cl_color
+#define CLS_LANES 512u                    // k_cl_solve: 8 waves, so that a lane may keep ...
+#define CLS_R 2u                          // ... the first contact row of this many manifolds in registers (256 VGPRs per lane at 2 waves per SIMD)
+#define CL_UNASSIGNED 0xFFFFFFFFu
+#define CL_WEIGHT_MANIFOLD 64u            // weight of a manifold on the curve ...
+#define CL_WEIGHT_EXTRA 48u               // ... plus this per contact beyond the first (they cost LDS rows)
+#define CL_TASK_MAX_MANIFOLDS 2048u       // hard limits of k_cl_color's LDS tables (a task normally holds <= taskManifolds + one body's degree)
+#define CL_TASK_MAX_BODIES 2047u
+#define CL_HASH_SIZE 4096u
+#define CL_LOCAL_STATIC 0xFFFFu           // local body index of the static dummy body
+#define CL_SERIAL_COLOR 64u
+#define CL_SPIN_LIMIT (1u << 22)          // polls before a lane gives up: only reached when the workgroups are not all resident
+
+MI_DEV u32 clOrderedBits(float f) { u32 b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+MI_DEV float clOrderedFloat(u32 o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o); }
+MI_DEV u32 clSpread10(u32 x) { x &= 0x3FFu; x = (x | (x << 16)) & 0x030000FFu; x = (x | (x << 8)) & 0x0300F00Fu; x = (x | (x << 4)) & 0x030C30C3u; x = (x | (x << 2)) & 0x09249249u; return x; }
+MI_DEV u32 clHash(u32 x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Body order: bounding box of the centres of gravity, Morton keys per phase, radix sort, ranks.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cl_bbox(u32 nb, const float4* __restrict__ cog, const uint8_t* __restrict__ simMask, u32* __restrict__ counters)
+{
+	float mn[3] = { MI_FLT_MAX, MI_FLT_MAX, MI_FLT_MAX }, mx[3] = { -MI_FLT_MAX, -MI_FLT_MAX, -MI_FLT_MAX };
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x)
+	{
+		if (!simMask[i]) continue;
+		float4 c = cog[i];
+		if (!(c.x == c.x && c.y == c.y && c.z == c.z)) continue;
+		mn[0] = fminf(mn[0], c.x); mn[1] = fminf(mn[1], c.y); mn[2] = fminf(mn[2], c.z);
+		mx[0] = fmaxf(mx[0], c.x); mx[1] = fmaxf(mx[1], c.y); mx[2] = fmaxf(mx[2], c.z);
+	}
+	for (int k = 0; k < 3; ++k)
+		for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+	if ((threadIdx.x & 63u) == 0u && mn[0] <= mx[0])
+		for (int k = 0; k < 3; ++k) { atomicMin(&counters[CTR_CL_BBOX + k], clOrderedBits(mn[k])); atomicMax(&counters[CTR_CL_BBOX + 3 + k], clOrderedBits(mx[k])); }
+}
+
+struct ClShifts { u32 s[CL_MAX_PARTS][3]; };
+
+__global__ void __launch_bounds__(256) k_cl_keys(u32 nb, u32 numParts, ClShifts shifts, u32 maxShift, const float4* __restrict__ cog, const uint8_t* __restrict__ simMask,
+	const u32* __restrict__ counters, u32* __restrict__ keys, u32* __restrict__ vals)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nb) return;
+	float lo[3], ext = 0.f;
+	for (int k = 0; k < 3; ++k)
+	{
+		lo[k] = clOrderedFloat(counters[CTR_CL_BBOX + k]);
+		float hi = clOrderedFloat(counters[CTR_CL_BBOX + 3 + k]);
+		ext = fmaxf(ext, hi - lo[k]);
+	}
+	float scale = (ext > 0.f) ? (float)(1023u - maxShift) / ext : 0.f; // one cell size for the three axes
+	float4 c = cog[i];
+	bool sim = simMask[i] != 0 && c.x == c.x && c.y == c.y && c.z == c.z;
+	int q[3] = { (int)((c.x - lo[0]) * scale), (int)((c.y - lo[1]) * scale), (int)((c.z - lo[2]) * scale) };
+	for (int k = 0; k < 3; ++k) q[k] = q[k] < 0 ? 0 : (q[k] > (int)(1023u - maxShift) ? (int)(1023u - maxShift) : q[k]);
+	for (u32 p = 0; p < numParts; ++p)
+	{
+		u32 key = clSpread10((u32)q[0] + shifts.s[p][0]) | (clSpread10((u32)q[1] + shifts.s[p][1]) << 1) | (clSpread10((u32)q[2] + shifts.s[p][2]) << 2);
+		keys[(size_t)p * nb + i] = sim ? key : 0x3FFFFFFFu; // bodies simulated elsewhere sort last; no manifold refers to them
+		vals[(size_t)p * nb + i] = i;
+	}
+}
+
+__global__ void __launch_bounds__(256) k_cl_ranks(u32 nb, u32 numParts, const u32* __restrict__ sortedBodies, u32* __restrict__ rank)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nb) return;
+	for (u32 p = 0; p < numParts; ++p) rank[(size_t)p * (nb + 1) + sortedBodies[(size_t)p * nb + i]] = i;
+	if (i == 0) for (u32 p = 0; p < numParts; ++p) rank[(size_t)p * (nb + 1) + nb] = 0xFFFFFFFFu; // the static dummy owns nothing
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Assignment.  wsum[r] = weight of the not-yet-assigned manifolds OWNED by the body of rank r (owner = the dynamic body of the
+// manifold that comes first on this phase's curve); cum = exclusive scan; task of a body = cum / taskWeight; a manifold whose
+// dynamic bodies agree on the task is interior to it.  Whatever a task holds is owned by its bodies, so a task's weight is below
+// taskWeight + one body's weight.
+// ---------------------------------------------------------------------------------------------------------------
+// Bid of a manifold for its bodies in a colouring round: lowest wins.  Manifolds with more contacts bid lower, so they are coloured
+// first and gather in the low colours: a colour's sweep time is that of its longest manifold, and this keeps the 2-4-contact ones
+// (20 % of a mixed pile) out of most colours.  Then a pseudo-random priority (hash of the narrowphase slot and the round), then
+// the position inside the task, which makes the bid unique.
+MI_DEV u32 clBid(u32 slot, u32 count, u32 round, u32 i) { return ((4u - count) << 30) | ((clHash(slot * 2654435761u + round) & 0x3FFFFu) << 12) | i; }
+MI_DEV u32 clWeight(u32 count) { return CL_WEIGHT_MANIFOLD + (count - 1u) * CL_WEIGHT_EXTRA; }
+
+__global__ void __launch_bounds__(256) k_cl_weights0(const u32* __restrict__ counters, u32 nb, const uint4* __restrict__ actIds, const u32* __restrict__ rank0,
+	u32* __restrict__ wsum, u32* __restrict__ taskKey)
+{
+	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= counters[CTR_NUM_ACTIVE]) return;
+	uint4 ids = actIds[j];
+	u32 ra = rank0[ids.x], rb = rank0[ids.y]; // the dummy's rank is 0xFFFFFFFF
+	atomicAdd(&wsum[min(ra, rb)], clWeight(ids.z));
+	taskKey[j] = CL_UNASSIGNED;
+}
+
+// Phase p: assign what is interior; what is left adds its weight to the next phase's curve, or (last partition) goes to the rest task.
+__global__ void __launch_bounds__(256) k_cl_assign(const u32* __restrict__ counters, u32 nb, u32 phase, u32 numParts, u32 taskWeight, const uint4* __restrict__ actIds,
+	const u32* __restrict__ rank, const u32* __restrict__ cum, const u32* __restrict__ rankNext, u32* __restrict__ wsumNext,
+	u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask, u32* __restrict__ status)
+{
+	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= counters[CTR_NUM_ACTIVE]) return;
+	if (taskKey[j] != CL_UNASSIGNED) return;
+	uint4 ids = actIds[j];
+	u32 a = ids.x, b = ids.y;
+	bool da = a < nb, db = b < nb;
+	u32 ta = da ? cum[rank[a]] / taskWeight : 0u, tb = db ? cum[rank[b]] / taskWeight : 0u;
+	if (!da) ta = tb;
+	if (!db) tb = ta;
+	u32 key = CL_UNASSIGNED;
+	if (ta == tb)
+	{
+		if (ta >= CL_MAX_TASKS) { atomicOr(status, 1u); ta = CL_MAX_TASKS - 1u; }
+		key = phase * CL_MAX_TASKS + ta;
+	}
+	else if (phase + 1u == numParts) key = numParts * CL_MAX_TASKS; // the rest task
+	if (key != CL_UNASSIGNED)
+	{
+		u32 ph = key / CL_MAX_TASKS;
+		taskKey[j] = key;
+		taskPos[j] = atomicAdd(&taskCount[key], 1u);
+		if (da) atomicOr(&phaseMask[a], 1u << ph);
+		if (db) atomicOr(&phaseMask[b], 1u << ph);
+	}
+	else
+	{
+		u32 ra = rankNext[a], rb = rankNext[b];
+		atomicAdd(&wsumNext[min(ra, rb)], clWeight(ids.z));
+	}
+}
+
+// One workgroup: exclusive scan of the per-task counts -> first slot of every task; tasks per phase; end of schedule.
+__global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters, u32 numParts, const u32* __restrict__ taskCount, u32* __restrict__ taskStart)
+{
+	__shared__ u32 part[1024];
+	__shared__ u32 lastTask[CL_MAX_PHASES];
+	const u32 total = CL_MAX_PHASES * CL_MAX_TASKS, per = total / 1024u;
+	u32 t = threadIdx.x;
+	if (t < CL_MAX_PHASES) lastTask[t] = 0;
+	u32 sum = 0;
+	for (u32 k = 0; k < per; ++k) sum += taskCount[t * per + k];
+	part[t] = sum;
+	__syncthreads();
+	for (u32 o = 1; o < 1024u; o <<= 1) { u32 v = (t >= o) ? part[t - o] : 0u; __syncthreads(); part[t] += v; __syncthreads(); }
+	u32 run = part[t] - sum;
+	for (u32 k = 0; k < per; ++k)
+	{
+		u32 key = t * per + k, c = taskCount[key];
+		taskStart[key] = run; run += c;
+		if (c) atomicMax(&lastTask[key / CL_MAX_TASKS], (key % CL_MAX_TASKS) + 1u);
+	}
+	if (t == 1023u) taskStart[total] = run;
+	__syncthreads();
+	if (t <= numParts) counters[CTR_CL_NUM_TASKS + t] = lastTask[t];
+	else if (t < CL_MAX_PHASES) counters[CTR_CL_NUM_TASKS + t] = 0;
+	if (t == 0)
+	{
+		counters[CTR_NUM_MANIFOLDS] = part[1023];
+		counters[CTR_NUM_COLORS] = 0; // k_cl_color: atomicMax of the local colour counts
+		for (int k = 0; k < 3; ++k) { counters[CTR_CL_BBOX + k] = 0xFFFFFFFFu; counters[CTR_CL_BBOX + 3 + k] = 0u; } // consumed by k_cl_keys: ready for the next step
+	}
+}
+
+__global__ void __launch_bounds__(256) k_cl_scatter(const u32* __restrict__ counters, const u32* __restrict__ taskKey, const u32* __restrict__ taskPos, const u32* __restrict__ taskStart, u32* __restrict__ pre)
+{
+	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= counters[CTR_NUM_ACTIVE]) return;
+	pre[taskStart[taskKey[j]] + taskPos[j]] = j;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per task, one workgroup: local body table, local colouring, order by (colour, 4 - contacts), task header.
+//   LDS: body hash (global id -> local index), per local body a 64-bit colour mask and a claim word, per manifold its two local
+//   bodies, its key and its final position.
+// Colouring = the rounds of k_color_round with LDS atomics: every uncoloured manifold bids for both bodies with a pseudo-random
+// priority (deterministic: hash of its narrowphase slot and the round); who holds both takes the lowest colour free on both.
+// Manifolds that find no colour below 64 form the task's serial tail (one per barrier).
+// Local indices: bodies touched in more than one phase ("shared") first, then the task-private ones.
+// ---------------------------------------------------------------------------------------------------------------
+struct ClTask
+{
+	u32 first, count, numBodies, numShared, numColors, serialStart, numRows, pad;
+	u32 colorStart[72]; // position (relative to first) of the first manifold of colour c; [numColors] = serialStart
+};
+static_assert(sizeof(ClTask) == 320, "task header");
+
+__global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u32 nb, const u32* __restrict__ taskStart, const u32* __restrict__ pre, const uint4* __restrict__ actIds,
+	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ mExtra)
+{
+	extern __shared__ u32 clds[];
+	u32* hKey = clds;                                   // [CL_HASH_SIZE] global id + 1, 0 = empty
+	u32* hVal = hKey + CL_HASH_SIZE;                    // [CL_HASH_SIZE] local index
+	u64* mask = (u64*)(hVal + CL_HASH_SIZE);            // [CL_TASK_MAX_BODIES + 1]
+	u32* claim = (u32*)(mask + CL_TASK_MAX_BODIES + 1); // [CL_TASK_MAX_BODIES + 1]
+	u32* mAB = claim + CL_TASK_MAX_BODIES + 1;          // [CL_TASK_MAX_MANIFOLDS] la | lb << 16
+	u32* mKey = mAB + CL_TASK_MAX_MANIFOLDS;            // [..] colour * 4 + (4 - count); UNCOLORED while colouring
+	u32* mPos = mKey + CL_TASK_MAX_MANIFOLDS;           // [..] final position
+	u32* mCnt = mPos + CL_TASK_MAX_MANIFOLDS;           // [..] contact count by final position, then its exclusive scan of (count - 1)
+	u32* hist = mCnt + CL_TASK_MAX_MANIFOLDS;           // [264] per key, then cursors
+	__shared__ u32 sNumShared, sNumPrivate, sLeft, sMaxColor, sScan[16];
+	const u32 tid = threadIdx.x;
+	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
+
+	for (u32 key = blockIdx.x; key < totalKeys; key += gridDim.x)
+	{
+		u32 first = taskStart[key], n = taskStart[key + 1] - first;
+		ClTask* T = tasks + key;
+		if (!n) { if (tid == 0) { T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } continue; }
+		if (n > CL_TASK_MAX_MANIFOLDS) { if (tid == 0) { atomicOr(&counters[CTR_CL_STATUS], 2u); T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } continue; }
+		u32 phase = key / CL_MAX_TASKS;
+		for (u32 h = tid; h < CL_HASH_SIZE; h += CL_LANES) hKey[h] = 0;
+		for (u32 h = tid; h < 264u; h += CL_LANES) hist[h] = 0;
+		if (tid == 0) { sNumShared = 0; sNumPrivate = 0; sMaxColor = 0; }
+		__syncthreads();
+		// 1. distinct dynamic bodies
+		for (u32 i = tid; i < n; i += CL_LANES)
+		{
+			uint4 ids = actIds[pre[first + i]];
+			for (u32 e = 0; e < 2; ++e)
+			{
+				u32 g = e ? ids.y : ids.x;
+				if (g >= nb) continue;
+				u32 h = clHash(g) & (CL_HASH_SIZE - 1u);
+				for (;;)
+				{
+					u32 old = atomicCAS(&hKey[h], 0u, g + 1u);
+					if (old == 0u || old == g + 1u) break;
+					h = (h + 1u) & (CL_HASH_SIZE - 1u);
+				}
+			}
+		}
+		__syncthreads();
+		for (u32 h = tid; h < CL_HASH_SIZE; h += CL_LANES)
+			if (hKey[h])
+			{
+				bool shared = __popc(phaseMask[hKey[h] - 1u]) > 1;
+				hVal[h] = shared ? (atomicAdd(&sNumShared, 1u) | 0x80000000u) : atomicAdd(&sNumPrivate, 1u);
+			}
+		__syncthreads();
+		const u32 numShared = sNumShared, numBodies = sNumShared + sNumPrivate;
+		const bool tooMany = numBodies > CL_TASK_MAX_BODIES; // uniform
+		if (tooMany) { if (tid == 0) { atomicOr(&counters[CTR_CL_STATUS], 2u); T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } __syncthreads(); continue; }
+		for (u32 h = tid; h < CL_HASH_SIZE; h += CL_LANES)
+			if (hKey[h])
+			{
+				u32 v = hVal[h];
+				u32 l = (v & 0x80000000u) ? (v & 0x7FFFFFFFu) : numShared + v;
+				hVal[h] = l;
+				bodyList[(size_t)key * CL_BODY_STRIDE + l] = hKey[h] - 1u;
+			}
+		for (u32 l = tid; l <= numBodies; l += CL_LANES) { mask[l] = 0ull; claim[l] = 0xFFFFFFFFu; }
+		__syncthreads();
+		// 2. local ids of every manifold
+		for (u32 i = tid; i < n; i += CL_LANES)
+		{
+			uint4 ids = actIds[pre[first + i]];
+			u32 loc[2];
+			for (u32 e = 0; e < 2; ++e)
+			{
+				u32 g = e ? ids.y : ids.x;
+				loc[e] = CL_LOCAL_STATIC;
+				if (g >= nb) continue;
+				u32 h = clHash(g) & (CL_HASH_SIZE - 1u);
+				while (hKey[h] != g + 1u) h = (h + 1u) & (CL_HASH_SIZE - 1u);
+				loc[e] = hVal[h];
+			}
+			mAB[i] = loc[0] | (loc[1] << 16);
+			mKey[i] = 0xFFFFFFFFu;
+		}
+		__syncthreads();
+		// 3. colouring rounds
+		for (u32 round = 0; ; ++round)
+		{
+			if (tid == 0) sLeft = 0;
+			for (u32 i = tid; i < n; i += CL_LANES)
+			{
+				if (mKey[i] != 0xFFFFFFFFu) continue;
+				uint4 idq = actIds[pre[first + i]];
+				u32 slot = idq.w;
+				u32 bid = clBid(slot, idq.z, round, i);
+				u32 ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16;
+				if (la != CL_LOCAL_STATIC) atomicMin(&claim[la], bid);
+				if (lb != CL_LOCAL_STATIC) atomicMin(&claim[lb], bid);
+			}
+			__syncthreads();
+			u32 left = 0;
+			for (u32 i = tid; i < n; i += CL_LANES)
+			{
+				if (mKey[i] != 0xFFFFFFFFu) continue;
+				uint4 ids = actIds[pre[first + i]];
+				u32 bid = clBid(ids.w, ids.z, round, i);
+				u32 ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16;
+				bool won = (la == CL_LOCAL_STATIC || claim[la] == bid) && (lb == CL_LOCAL_STATIC || claim[lb] == bid);
+				if (!won) { ++left; continue; }
+				u64 used = (la != CL_LOCAL_STATIC ? mask[la] : 0ull) | (lb != CL_LOCAL_STATIC ? mask[lb] : 0ull);
+				u32 c = (~used) ? (u32)__ffsll((long long)~used) - 1u : CL_SERIAL_COLOR;
+				if (c < CL_SERIAL_COLOR)
+				{
+					if (la != CL_LOCAL_STATIC) mask[la] |= 1ull << c; // the only winner on this body in this round
+					if (lb != CL_LOCAL_STATIC) mask[lb] |= 1ull << c;
+					atomicMax(&sMaxColor, c + 1u);
+				}
+				mKey[i] = c * 4u + (4u - ids.z);
+			}
+			if (left) atomicAdd(&sLeft, left);
+			__syncthreads();
+			for (u32 l = tid; l < numBodies; l += CL_LANES) claim[l] = 0xFFFFFFFFu;
+			bool done = sLeft == 0u;
+			__syncthreads();
+			if (done) break;
+		}
+		// 4. order by key: histogram, scan by one wave, cursors
+		for (u32 i = tid; i < n; i += CL_LANES) atomicAdd(&hist[mKey[i]], 1u);
+		__syncthreads();
+		if (tid < 64u) // 260 keys, 5 per lane (65 colours x 4 counts): serial scan over 64 lanes
+		{
+			u32 base = tid * 5u, s = 0;
+			u32 v[5];
+			for (u32 k = 0; k < 5u; ++k) { v[k] = (base + k < 260u) ? hist[base + k] : 0u; s += v[k]; }
+			u32 incl = s;
+			for (int o = 1; o < 64; o <<= 1) { u32 up = __shfl_up(incl, o); if ((int)tid >= o) incl += up; }
+			u32 run = incl - s;
+			for (u32 k = 0; k < 5u; ++k) { if (base + k < 260u) hist[base + k] = run; run += v[k]; }
+		}
+		__syncthreads();
+		const u32 numColors = sMaxColor;
+		if (tid <= CL_SERIAL_COLOR) T->colorStart[tid] = hist[tid * 4u];
+		if (tid == 0)
+		{
+			T->first = first; T->count = n; T->numBodies = numBodies; T->numShared = numShared; T->numColors = numColors; T->serialStart = hist[CL_SERIAL_COLOR * 4u];
+			T->colorStart[CL_SERIAL_COLOR + 1u] = n;
+			atomicMax(&counters[CTR_NUM_COLORS], numColors + (hist[CL_SERIAL_COLOR * 4u] < n ? 1u : 0u));
+			atomicAdd(&counters[CTR_CL_SHARED], numShared);
+			atomicAdd(&counters[CTR_CL_PHASE_COUNT + phase], n);
+		}
+		__syncthreads();
+		// Positions inside a (colour, count) class follow the narrowphase slot order, so the schedule is a deterministic function of
+		// the inputs: rank of the manifold among its class = number of class members with a smaller slot ... that is quadratic; use
+		// an atomic cursor (order inside a class is free: its manifolds share no body) and keep determinism of RESULTS, not of the order.
+		for (u32 i = tid; i < n; i += CL_LANES) { u32 p = atomicAdd(&hist[mKey[i]], 1u); mPos[i] = p; mCnt[p] = (4u - (mKey[i] & 3u)); }
+		__syncthreads();
+		// 5. extra-row offsets: exclusive scan of (count - 1) over the final positions (2 per lane)
+		{
+			u32 p0 = 2u * tid, e0 = (p0 < n) ? mCnt[p0] - 1u : 0u, e1 = (p0 + 1u < n) ? mCnt[p0 + 1u] - 1u : 0u;
+			u32 s = e0 + e1, incl = s;
+			for (int o = 1; o < 64; o <<= 1) { u32 up = __shfl_up(incl, o); if ((int)(tid & 63u) >= o) incl += up; }
+			if ((tid & 63u) == 63u) sScan[tid >> 6] = incl;
+			__syncthreads();
+			u32 waveBase = 0;
+			for (u32 wv = 0; wv < (tid >> 6); ++wv) waveBase += sScan[wv];
+			u32 excl = waveBase + incl - s;
+			__syncthreads();
+			if (p0 < n) mCnt[p0] = excl;
+			if (p0 + 1u < n) mCnt[p0 + 1u] = excl + e0;
+			if (tid == CL_LANES - 1u) T->numRows = n + waveBase + incl;
+		}
+		__syncthreads();
+		for (u32 i = tid; i < n; i += CL_LANES)
+		{
+			u32 p = mPos[i];
+			mOrder[first + p] = pre[first + i];
+			mKeySorted[first + p] = mKey[i];
+			mLocal[first + p] = mAB[i];
+			mExtra[first + p] = mCnt[p];
+		}
+		__syncthreads();
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The sweep.
+// ---------------------------------------------------------------------------------------------------------------
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+struct ClLocal // a task of this workgroup, in LDS
+{
+	u32 first, count, numBodies, numShared, numColors, serialStart, phase, key;
+	u32 bodyOff;   // float4 index of the task's bodies (2 float4 each)
+	u32 infoOff;   // u32 index (in float4 units * 4) of per-body {global id, turn info}
+	u32 metaOff;   // float4 index of the per-manifold meta (not for the register task): {la|lb<<16, key|extra<<10, -, -}, {n.xyz, friction}
+	u32 rowOff;    // float4 index of the row planes
+	u32 rowCap;    // rows of this task that live in LDS
+	u32 inRegs;    // the first contact row of every manifold sits in its lane's registers
+	u32 colorStart[66];
+};
+
+// Row r of a task's LDS row region: 6 float4 planes + 1 float2 plane, plane-major (consecutive rows -> consecutive addresses).
+MI_DEV void clLoadRowLds(ContactRow& r, const float4* lds, u32 rowOff, u32 rowCap, u32 row)
+{
+	const float4* P = lds + rowOff + row;
+	r.p0 = P[0]; r.p1 = P[rowCap]; r.p2 = P[2 * rowCap]; r.p3 = P[3 * rowCap]; r.p4 = P[4 * rowCap]; r.p5 = P[5 * rowCap];
+	r.lam = ((const float2*)(lds + rowOff + 6 * rowCap))[row];
+}
+MI_DEV void clStoreLambdaLds(float4* lds, u32 rowOff, u32 rowCap, u32 row, float2 lam) { ((float2*)(lds + rowOff + 6 * rowCap))[row] = lam; }
+
+struct ClArgs
+{
+	u32* counters; const ClTask* tasks; const u32* bodyList; const u32* phaseMask;
+	const u32* mKeySorted; const u32* mLocal; const u32* mExtra;
+	const float4* rowPlanes; const float4* rowShared; float2* rowLambda;
+	float4* vel; u64* flow;
+	size_t rowCap; u32 nb, numParts, flowBytes, epoch, itBegin, itEnd, ldsFloat4s;
+};
+
+// One manifold: both bodies from LDS, its rows (registers / LDS / global memory), both bodies back.
+template <bool REG> MI_DEV void clSolveManifold(float4* lds, const ClLocal& L, const ClArgs& A, u32 pos, u32 ab, u32 keyExtra, float4 sh, ContactRow& r0)
+{
+	u32 la = ab & 0xFFFFu, lb = ab >> 16;
+	u32 count = 4u - (keyExtra & 3u), extra = keyExtra >> 10;
+	float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0, b1 = a0;
+	if (la != CL_LOCAL_STATIC) { a0 = lds[L.bodyOff + 2 * la]; a1 = lds[L.bodyOff + 2 * la + 1]; }
+	if (lb != CL_LOCAL_STATIC) { b0 = lds[L.bodyOff + 2 * lb]; b1 = lds[L.bodyOff + 2 * lb + 1]; }
+	V3 vA = v3f4(a0), wA = v3f4(a1), vB = v3f4(b0), wB = v3f4(b1);
+	float invMassA = a0.w, invMassB = b0.w;
+	V3 n = v3(sh.x, sh.y, sh.z);
+	float friction = sh.w;
+	u32 slot = L.first + pos;
+	u32 rowBase = REG ? extra : pos + extra; // LDS row of contact 1 (register task) or contact 0
+	for (u32 k = 0; k < count; ++k)
+	{
+		if (REG && k == 0) { solveRow(r0, n, friction, invMassA, invMassB, vA, wA, vB, wB); continue; }
+		u32 row = rowBase + (REG ? k - 1u : k);
+		ContactRow cur;
+		if (row < L.rowCap)
+		{
+			clLoadRowLds(cur, lds, L.rowOff, L.rowCap, row);
+			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
+			clStoreLambdaLds(lds, L.rowOff, L.rowCap, row, cur.lam);
+		}
+		else // beyond the LDS budget: streamed from global memory every iteration
+		{
+			loadRow(cur, k, slot, A.rowCap, A.rowPlanes, A.rowLambda);
+			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
+			A.rowLambda[(size_t)k * A.rowCap + slot] = cur.lam;
+		}
+	}
+	if (la != CL_LOCAL_STATIC) { lds[L.bodyOff + 2 * la] = make_float4(vA.x, vA.y, vA.z, invMassA); lds[L.bodyOff + 2 * la + 1] = make_float4(wA.x, wA.y, wA.z, 0.f); }
+	if (lb != CL_LOCAL_STATIC) { lds[L.bodyOff + 2 * lb] = make_float4(vB.x, vB.y, vB.z, invMassB); lds[L.bodyOff + 2 * lb + 1] = make_float4(wB.x, wB.y, wB.z, 0.f); }
+}
+
+__global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
+{
+	extern __shared__ float4 lds[];
+	__shared__ ClLocal sTask[CL_MAX_PHASES];
+	__shared__ u32 sNumTasks, sAbort;
+	const u32 tid = threadIdx.x, G = gridDim.x;
+	u32* status = A.counters + CTR_FLOW_STATUS;
+	__amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(A.flow, 0, A.flowBytes, 0x00020000);
+
+	// ---- which tasks are mine, and where they live in LDS ----
+	if (tid == 0)
+	{
+		u32 nT = 0, off = 0, used = 0; // used: float4s of LDS handed out
+		bool bad = A.counters[CTR_CL_STATUS] != 0u;
+		for (u32 p = 0; p <= A.numParts; ++p)
+		{
+			u32 tasksInPhase = A.counters[CTR_CL_NUM_TASKS + p];
+			if (tasksInPhase > G) bad = true;
+			// task t of phase p runs on workgroup (off + t) % G
+			u32 t = (blockIdx.x + G - (off % G)) % G;
+			off += tasksInPhase;
+			if (t >= tasksInPhase) continue;
+			u32 key = p * CL_MAX_TASKS + t;
+			const ClTask* T = A.tasks + key;
+			if (!T->count) continue;
+			ClLocal& L = sTask[nT];
+			L.first = T->first; L.count = T->count; L.numBodies = T->numBodies; L.numShared = T->numShared; L.numColors = T->numColors; L.serialStart = T->serialStart;
+			L.phase = p; L.key = key;
+			for (u32 c = 0; c <= CL_SERIAL_COLOR + 1u; ++c) L.colorStart[c] = T->colorStart[c];
+			L.bodyOff = used; used += 2u * L.numBodies;
+			L.infoOff = used * 4u; used += (2u * L.numBodies + 3u) / 4u;
+			L.inRegs = (nT == 0 && L.count <= CLS_LANES * CLS_R) ? 1u : 0u;
+			L.metaOff = used; if (!L.inRegs) used += 2u * L.count;
+			L.rowOff = 0; L.rowCap = 0;
+			++nT;
+		}
+		// rows: whatever LDS is left, in task order (7 plane-rows of 16 B per row: 6 float4 + 1 float2 rounded up)
+		for (u32 k = 0; k < nT; ++k)
+		{
+			ClLocal& L = sTask[k];
+			u32 want = A.tasks[L.key].numRows - (L.inRegs ? L.count : 0u);
+			u32 left = (used + 1u < A.ldsFloat4s) ? A.ldsFloat4s - used - 1u : 0u; // one float4 stays free: the static dummy never needs it, keeps offsets in range
+			u32 fit = (u32)(((u64)left * 2u) / 13u);     // 6.5 float4 per row
+			u32 cap = want < fit ? want : fit;
+			L.rowOff = used; L.rowCap = cap; used += (13u * cap + 1u) / 2u;
+		}
+		if (used > A.ldsFloat4s) bad = true; // bodies + meta alone exceed LDS: cannot run this launch
+		if (bad) atomicOr(status, 64u);
+		sNumTasks = nT; sAbort = (bad || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1u : 0u;
+	}
+	__syncthreads();
+	if (sAbort) return; // uniform: the launch cannot run (or somebody has given up already); the host redoes the step
+	const u32 numTasks = sNumTasks;
+	if (!numTasks) return;
+
+	// ---- prologue: bodies, meta, rows ----
+	static_assert(CLS_R == 2u, "two named register sets below");
+	u32 regAB0 = 0, regAB1 = 0, regKE0 = 0xFFFFFFFFu, regKE1 = 0xFFFFFFFFu; float4 regSh0 = make_float4(0.f, 0.f, 0.f, 0.f), regSh1 = regSh0; ContactRow regRow0 = {}, regRow1 = {}, noRow = {};
+	for (u32 k = 0; k < numTasks; ++k)
+	{
+		const ClLocal& L = sTask[k];
+		u32* info = (u32*)lds + L.infoOff;
+		for (u32 l = tid; l < L.numBodies; l += CLS_LANES)
+		{
+			u32 g = A.bodyList[(size_t)L.key * CL_BODY_STRIDE + l];
+			u32 pm = A.phaseMask[g];
+			u32 deg = __popc(pm), rank = __popc(pm & ((1u << L.phase) - 1u));
+			info[2 * l] = g; info[2 * l + 1] = deg | (rank << 8);
+			lds[L.bodyOff + 2 * l] = A.vel[2 * g]; lds[L.bodyOff + 2 * l + 1] = A.vel[2 * g + 1]; // shared ones too: .w = invMass stays, the rest is replaced at every acquire
+		}
+		if (L.inRegs)
+		{
+#define CL_LOAD_REG(R_, AB_, KE_, SH_, ROW_) \
+			{ \
+				u32 i = tid + (R_) * CLS_LANES; \
+				if (i < L.count) \
+				{ \
+					u32 slot = L.first + i; \
+					u32 key = A.mKeySorted[slot], extra = A.mExtra[slot], count = 4u - (key & 3u); \
+					AB_ = A.mLocal[slot]; KE_ = key | (extra << 10); SH_ = A.rowShared[slot]; \
+					loadRow(ROW_, 0, slot, A.rowCap, A.rowPlanes, A.rowLambda); \
+					for (u32 kk = 1; kk < count; ++kk) \
+					{ \
+						u32 row = extra + kk - 1u; \
+						if (row >= L.rowCap) continue; \
+						ContactRow cur; \
+						loadRow(cur, kk, slot, A.rowCap, A.rowPlanes, A.rowLambda); \
+						float4* P = lds + L.rowOff + row; \
+						P[0] = cur.p0; P[L.rowCap] = cur.p1; P[2 * L.rowCap] = cur.p2; P[3 * L.rowCap] = cur.p3; P[4 * L.rowCap] = cur.p4; P[5 * L.rowCap] = cur.p5; \
+						clStoreLambdaLds(lds, L.rowOff, L.rowCap, row, cur.lam); \
+					} \
+				} \
+			}
+			CL_LOAD_REG(0u, regAB0, regKE0, regSh0, regRow0)
+			CL_LOAD_REG(1u, regAB1, regKE1, regSh1, regRow1)
+#undef CL_LOAD_REG
+		}
+		else for (u32 i = tid; i < L.count; i += CLS_LANES)
+		{
+			u32 slot = L.first + i;
+			u32 key = A.mKeySorted[slot], extra = A.mExtra[slot], count = 4u - (key & 3u);
+			lds[L.metaOff + 2 * i] = make_float4(__uint_as_float(A.mLocal[slot]), __uint_as_float(key | (extra << 10)), 0.f, 0.f);
+			lds[L.metaOff + 2 * i + 1] = A.rowShared[slot];
+			for (u32 kk = 0; kk < count; ++kk)
+			{
+				u32 row = i + extra + kk;
+				if (row >= L.rowCap) continue;
+				ContactRow cur;
+				loadRow(cur, kk, slot, A.rowCap, A.rowPlanes, A.rowLambda);
+				float4* P = lds + L.rowOff + row;
+				P[0] = cur.p0; P[L.rowCap] = cur.p1; P[2 * L.rowCap] = cur.p2; P[3 * L.rowCap] = cur.p3; P[4 * L.rowCap] = cur.p4; P[5 * L.rowCap] = cur.p5;
+				clStoreLambdaLds(lds, L.rowOff, L.rowCap, row, cur.lam);
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- iterations ----
+	bool aborted = false;
+	for (u32 it = A.itBegin; it < A.itEnd && !aborted; ++it)
+	{
+		for (u32 k = 0; k < numTasks; ++k)
+		{
+			const ClLocal& L = sTask[k];
+			const u32* info = (const u32*)lds + L.infoOff;
+			// acquire the bodies other phases also touch
+			for (u32 l = tid; l < L.numShared; l += CLS_LANES)
+			{
+				u32 g = info[2 * l], ti = info[2 * l + 1];
+				u32 deg = ti & 0xFFu, rank = ti >> 8;
+				u32 want = A.epoch + (it - A.itBegin) * deg + rank;
+				if (it == A.itBegin && rank == 0u) continue; // first user of the launch: the prologue's copy of vel is current
+				u32 spins = 0;
+				for (;;)
+				{
+					asm volatile("" ::: "memory");
+					u32x4 h0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64u, 0, 16);
+					u32x4 h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64u + 16u, 0, 16);
+					if (h0.w == want && h1.w == want)
+					{
+						float invMass = lds[L.bodyOff + 2 * l].w; // constant over the launch
+						lds[L.bodyOff + 2 * l] = make_float4(__uint_as_float(h0.x), __uint_as_float(h0.y), __uint_as_float(h0.z), invMass);
+						lds[L.bodyOff + 2 * l + 1] = make_float4(__uint_as_float(h1.x), __uint_as_float(h1.y), __uint_as_float(h1.z), 0.f);
+						break;
+					}
+					if (++spins > CL_SPIN_LIMIT) { atomicOr(status, 1u); sAbort = 1u; break; }
+					if ((spins & 63u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { sAbort = 1u; break; }
+					__builtin_amdgcn_s_sleep(1);
+				}
+			}
+			__syncthreads();
+			if (sAbort) { aborted = true; break; }
+			// colours
+			if (L.inRegs)
+			{
+				const u32 col0 = (regKE0 & 0x3FFu) >> 2, col1 = (regKE1 & 0x3FFu) >> 2; // 255 = no manifold: matches no colour
+				for (u32 c = 0; c < L.numColors; ++c)
+				{
+					if (col0 == c) clSolveManifold<true>(lds, L, A, tid, regAB0, regKE0, regSh0, regRow0);
+					if (col1 == c) clSolveManifold<true>(lds, L, A, tid + CLS_LANES, regAB1, regKE1, regSh1, regRow1);
+					__syncthreads();
+				}
+				for (u32 s = L.serialStart; s < L.count; ++s)
+				{
+					if (tid == s) clSolveManifold<true>(lds, L, A, s, regAB0, regKE0, regSh0, regRow0);
+					if (tid + CLS_LANES == s) clSolveManifold<true>(lds, L, A, s, regAB1, regKE1, regSh1, regRow1);
+					__syncthreads();
+				}
+			}
+			else
+			{
+				for (u32 c = 0; c < L.numColors; ++c)
+				{
+					for (u32 i = L.colorStart[c] + tid; i < L.colorStart[c + 1]; i += CLS_LANES)
+					{
+						float4 m0 = lds[L.metaOff + 2 * i], sh = lds[L.metaOff + 2 * i + 1];
+						clSolveManifold<false>(lds, L, A, i, __float_as_uint(m0.x), __float_as_uint(m0.y), sh, noRow);
+					}
+					__syncthreads();
+				}
+				for (u32 s = L.serialStart; s < L.count; ++s)
+				{
+					if (tid == 0)
+					{
+						float4 m0 = lds[L.metaOff + 2 * s], sh = lds[L.metaOff + 2 * s + 1];
+						clSolveManifold<false>(lds, L, A, s, __float_as_uint(m0.x), __float_as_uint(m0.y), sh, noRow);
+					}
+					__syncthreads();
+				}
+			}
+			// hand the shared bodies on
+			for (u32 l = tid; l < L.numShared; l += CLS_LANES)
+			{
+				u32 g = info[2 * l], ti = info[2 * l + 1];
+				u32 deg = ti & 0xFFu, rank = ti >> 8;
+				u32 want = A.epoch + (it - A.itBegin) * deg + rank;
+				float4 b0 = lds[L.bodyOff + 2 * l], b1 = lds[L.bodyOff + 2 * l + 1];
+				if (it + 1u == A.itEnd && rank + 1u == deg) { A.vel[2 * g] = b0; A.vel[2 * g + 1] = make_float4(b1.x, b1.y, b1.z, 0.f); } // last user of the launch
+				else
+				{
+					u32x4 h1 = { __float_as_uint(b1.x), __float_as_uint(b1.y), __float_as_uint(b1.z), want + 1u };
+					u32x4 h0 = { __float_as_uint(b0.x), __float_as_uint(b0.y), __float_as_uint(b0.z), want + 1u };
+					__builtin_amdgcn_raw_buffer_store_b128(h1, rsrc, g * 64u + 16u, 0, 16);
+					__builtin_amdgcn_raw_buffer_store_b128(h0, rsrc, g * 64u, 0, 16);
+				}
+			}
+		}
+	}
+	if (aborted) return; // the host redoes the step (World::recoverSolve)
+
+	// ---- epilogue: task-private bodies and the accumulated impulses go home ----
+	for (u32 k = 0; k < numTasks; ++k)
+	{
+		const ClLocal& L = sTask[k];
+		const u32* info = (const u32*)lds + L.infoOff;
+		for (u32 l = L.numShared + tid; l < L.numBodies; l += CLS_LANES)
+		{
+			u32 g = info[2 * l];
+			float4 b1 = lds[L.bodyOff + 2 * l + 1];
+			A.vel[2 * g] = lds[L.bodyOff + 2 * l]; A.vel[2 * g + 1] = make_float4(b1.x, b1.y, b1.z, 0.f);
+		}
+		if (L.inRegs)
+		{
+#define CL_STORE_REG(R_, KE_, ROW_) \
+			{ \
+				u32 i = tid + (R_) * CLS_LANES; \
+				if (i < L.count) \
+				{ \
+					u32 slot = L.first + i, count = 4u - (KE_ & 3u), extra = KE_ >> 10; \
+					A.rowLambda[slot] = ROW_.lam; \
+					for (u32 kk = 1; kk < count; ++kk) \
+					{ \
+						u32 row = extra + kk - 1u; \
+						if (row < L.rowCap) A.rowLambda[(size_t)kk * A.rowCap + slot] = ((const float2*)(lds + L.rowOff + 6 * L.rowCap))[row]; \
+					} \
+				} \
+			}
+			CL_STORE_REG(0u, regKE0, regRow0)
+			CL_STORE_REG(1u, regKE1, regRow1)
+#undef CL_STORE_REG
+		}
+		else for (u32 i = tid; i < L.count; i += CLS_LANES)
+		{
+			u32 slot = L.first + i;
+			u32 keyExtra = __float_as_uint(lds[L.metaOff + 2 * i].y);
+			u32 count = 4u - (keyExtra & 3u), extra = keyExtra >> 10;
+			for (u32 kk = 0; kk < count; ++kk)
+			{
+				u32 row = i + extra + kk;
+				if (row < L.rowCap) A.rowLambda[(size_t)kk * A.rowCap + slot] = ((const float2*)(lds + L.rowOff + 6 * L.rowCap))[row];
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------------------------------------------
+static size_t clColorLdsBytes()
+{
+	return sizeof(u32) * (2 * CL_HASH_SIZE + (CL_TASK_MAX_BODIES + 1) + 4 * CL_TASK_MAX_MANIFOLDS + 264) + sizeof(u64) * (CL_TASK_MAX_BODIES + 1);
+}
+
+bool cluster_available(World& w)
+{
+	if (w.clusterLdsBytes) return w.clusterLdsBytes != ~0u;
+	int maxLds = 0, cus = 0;
+	MI_CHECK(hipDeviceGetAttribute(&maxLds, hipDeviceAttributeMaxSharedMemoryPerBlock, w.device));
+	MI_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w.device));
+	hipFuncAttributes fa = {};
+	MI_CHECK(hipFuncGetAttributes(&fa, (const void*)k_cl_solve));
+	size_t dyn = (maxLds > 0 ? (size_t)maxLds : 65536) - fa.sharedSizeBytes - 256;
+	dyn &= ~(size_t)15;
+	if (hipFuncSetAttribute((const void*)k_cl_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess
+		|| hipFuncSetAttribute((const void*)k_cl_color, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clColorLdsBytes()) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		w.clusterLdsBytes = ~0u;
+		return false;
+	}
+	w.clusterLdsBytes = (u32)dyn; w.clusterBlocks = (u32)std::max(1, cus);
+	return true;
+}
+
+// Everything between "manifolds exist" and "rows can be initialised": order of the bodies, tasks, local colouring, final slot order.
+void launch_cluster_build(World& w, u32 numPairs)
+{
+	if (!numPairs) return;
+	u32 nb = w.nb, P = w.clusterParts;
+	size_t nb1 = (size_t)nb + 1;
+	w.clKeys.ensure((size_t)P * nb, w.stream); w.clKeysSorted.ensure((size_t)P * nb, w.stream); w.clVals.ensure((size_t)P * nb, w.stream); w.clSorted.ensure((size_t)P * nb, w.stream);
+	w.clRank.ensure((size_t)P * nb1, w.stream); w.clWsum.ensure(2 * nb1, w.stream); w.clCum.ensure(nb1, w.stream); w.clPhaseMask.ensure(nb1, w.stream);
+	w.clTaskKey.ensure(w.pairCap, w.stream); w.clTaskPos.ensure(w.pairCap, w.stream); w.clPre.ensure(w.pairCap, w.stream); w.clLocal.ensure(w.pairCap, w.stream); w.clExtra.ensure(w.pairCap, w.stream);
+	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
+	w.clTaskCount.ensure(totalKeys, w.stream); w.clTaskStart.ensure(totalKeys + 1, w.stream);
+	w.clTasks.ensure((size_t)totalKeys * sizeof(ClTask), w.stream); w.clBodyList.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream);
+	if (w.lastError) return;
+
+	dim3 bgrid((nb + 255) / 256), block(256), mgrid((numPairs + 255) / 256);
+	// active manifolds (k_active_list of the colouring: also counts contacts); no warm colours, no global colour masks
+	launch_active_list(w, numPairs);
+	// body order (any order is correct; this one makes the clusters compact)
+	ClShifts sh; u32 maxShift = 0;
+	for (u32 p = 0; p < CL_MAX_PARTS; ++p) for (u32 k = 0; k < 3; ++k) { sh.s[p][k] = w.clusterShift[p][k]; maxShift = std::max(maxShift, sh.s[p][k]); }
+	hipLaunchKernelGGL(k_cl_bbox, dim3(std::min<u32>(bgrid.x, 64u)), block, 0, w.stream, nb, w.cog.p, w.simMask.p, w.dCounters.p);
+	hipLaunchKernelGGL(k_cl_keys, bgrid, block, 0, w.stream, nb, P, sh, maxShift, w.cog.p, w.simMask.p, w.dCounters.p, w.clKeys.p, w.clVals.p);
+	for (u32 p = 0; p < P; ++p)
+		prim_sort_pairs_u32(w, w.clKeys.p + (size_t)p * nb, w.clKeysSorted.p + (size_t)p * nb, w.clVals.p + (size_t)p * nb, w.clSorted.p + (size_t)p * nb, nb, 30);
+	hipLaunchKernelGGL(k_cl_ranks, bgrid, block, 0, w.stream, nb, P, w.clSorted.p, w.clRank.p);
+	// tasks
+	MI_CHECK(hipMemsetAsync(w.clWsum.p, 0, sizeof(u32) * 2 * nb1, w.stream));
+	MI_CHECK(hipMemsetAsync(w.clPhaseMask.p, 0, sizeof(u32) * nb1, w.stream));
+	MI_CHECK(hipMemsetAsync(w.clTaskCount.p, 0, sizeof(u32) * totalKeys, w.stream));
+	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CL_STATUS, 0, sizeof(u32) * 8, w.stream)); // status, max colours, shared bodies, manifolds per phase
+	hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, w.clWsum.p, w.clTaskKey.p);
+	for (u32 p = 0; p < P; ++p)
+	{
+		u32* wsum = w.clWsum.p + (size_t)(p & 1u) * nb1; u32* wsumNext = w.clWsum.p + (size_t)((p + 1u) & 1u) * nb1;
+		prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
+		if (p + 1 < P) MI_CHECK(hipMemsetAsync(wsumNext, 0, sizeof(u32) * nb1, w.stream));
+		hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, P, w.clusterTaskWeight, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
+			w.clRank.p + (size_t)std::min(p + 1, P - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
+	}
+	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, P, w.clTaskCount.p, w.clTaskStart.p);
+	hipLaunchKernelGGL(k_cl_scatter, mgrid, block, 0, w.stream, w.dCounters.p, w.clTaskKey.p, w.clTaskPos.p, w.clTaskStart.p, w.clPre.p);
+	hipLaunchKernelGGL(k_cl_color, dim3(w.clusterBlocks), dim3(CL_LANES), clColorLdsBytes(), w.stream, w.dCounters.p, nb, w.clTaskStart.p, w.clPre.p, w.actIds.p,
+		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clExtra.p);
+}
+
+// Iterations [itBegin, itEnd) of the contact sweep in one launch.
+void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd)
+{
+	if (itBegin >= itEnd) return;
+	size_t words = (size_t)(w.nb + 1) * 8;
+	if (w.flow.cap < words) { w.flow.ensure(words, w.stream); w.flowEpoch = 0; }
+	if (w.flowEpoch == 0 || w.flowEpoch >= 0xFFFEu) // first use or the turn counter about to wrap: no stale record may ever match
+	{
+		MI_CHECK(hipMemsetAsync(w.flow.p, 0, sizeof(u64) * words, w.stream));
+		w.flowEpoch = 0;
+	}
+	w.flowEpoch++;
+	if (w.flowTestAbortStep == w.stats.numInternalSteps) // tests: pretend a lane timed out; everybody drains without solving
+	{
+		u32 one = 16u;
+		MI_CHECK(hipMemcpyAsync(w.dCounters.p + CTR_FLOW_STATUS, &one, sizeof(u32), hipMemcpyHostToDevice, w.stream));
+		MI_CHECK(hipStreamSynchronize(w.stream));
+	}
+	ClArgs A;
+	A.counters = w.dCounters.p; A.tasks = (const ClTask*)w.clTasks.p; A.bodyList = w.clBodyList.p; A.phaseMask = w.clPhaseMask.p;
+	A.mKeySorted = w.mKeySorted.p; A.mLocal = w.clLocal.p; A.mExtra = w.clExtra.p;
+	A.rowPlanes = w.rowPlanes.p; A.rowShared = w.rowShared.p; A.rowLambda = w.rowLambda.p; A.vel = w.vel.p; A.flow = w.flow.p;
+	A.rowCap = w.rowCap; A.nb = w.nb; A.numParts = w.clusterParts; A.flowBytes = (u32)(words * sizeof(u64)); A.epoch = w.flowEpoch << 16; A.itBegin = itBegin; A.itEnd = itEnd;
+	A.ldsFloat4s = w.clusterLdsBytes / 16u;
+	hipLaunchKernelGGL(k_cl_solve, dim3(w.clusterBlocks), dim3(CLS_LANES), w.clusterLdsBytes, w.stream, A);
+}

@@ -87,8 +87,18 @@ enum
 	CTR_EVENT_OVERFLOW = 417,// bit 0: the event ring was full, events were dropped; bit 1: a pair-set table was full
 	CTR_TERRAIN_BASE = 418, // first manifold slot of the terrain contacts (= number of pair manifold slots)
 	CTR_TERRAIN_OVERFLOW = 419,// more terrain contacts than slots: contacts were dropped (the host fails the world)
+	CTR_CL_NUM_TASKS = 424, // 4 words: cluster sweep: tasks of phase p (positions up to the last non-empty one)
+	CTR_CL_STATUS = 428,    // cluster build: bit 0 = more tasks in a phase than the table holds, bit 1 = a task exceeds k_cl_color's tables
+	CTR_CL_SHARED = 429,    // statistics: bodies handed between tasks (summed over tasks)
+	CTR_CL_PHASE_COUNT = 430,// 4 words: statistics: manifolds per phase
+	CTR_CL_BBOX = 436,      // 6 words: min xyz, max xyz of the simulated bodies' centres of gravity (order-preserving integer encoding)
 	CTR_WORDS = 512,
 };
+// Cluster sweep (k_cluster.hip): up to CL_MAX_PARTS partition phases + the rest phase; task key = phase * CL_MAX_TASKS + task.
+#define CL_MAX_PARTS 3u
+#define CL_MAX_PHASES (CL_MAX_PARTS + 1u)
+#define CL_MAX_TASKS 512u
+#define CL_BODY_STRIDE 2048u
 #define MI_NUM_SCHEDULE_KEYS ((MI_MAX_COLORS + 1) * 4)
 
 struct World
@@ -161,6 +171,13 @@ struct World
 	bool regionsReady = false, useFlowRegions = false; u32 flowRegions = 1; // XCD regions: MI_FLOW_REGIONS=1 (no measured gain yet)
 	u32 flowEagerMax = 131072;            // up to this many manifolds every poll fetches both record halves (MI_FLOW_EAGER)
 	u32 flowMaxManifolds = 0xFFFFFFFFu;   // the dataflow kernel takes the colours at the end of the schedule holding at most this many manifolds, launches the rest (MI_FLOW_MAX; default: everything)
+	// cluster sweep (k_cluster.hip)
+	bool useCluster = true;               // MI_PHYSICS_NO_CLUSTER=1: launch-per-colour sweep only
+	bool lastStepCluster = false, backupVelocities = false;
+	u32 clusterParts = 2, clusterTaskWeight = 64u * 960u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
+	u32 clusterLdsBytes = 0, clusterBlocks = 0, clusterCooldown = 0;
+	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clExtra, clTaskCount, clTaskStart, clBodyList;
+	DevBuf<uint8_t> clTasks;
 	DevBuf<u64> flowTrace;                // developer timeline (mi_debug_flow_trace): 32 x u64 per slot, allocated on request only
 	u32 flowEpoch = 0, flowMaxBlocks[2] = { 0, 0 };
 	bool useFlow = true;                  // MI_PHYSICS_NO_FLOW=1: launch-per-colour sweep only
@@ -242,6 +259,10 @@ void launch_coloring(World& w, u32 numPairs);
 void launch_contact_init(World& w, u32 numPairs, float dt);
 void launch_solve_contacts_iteration(World& w, const u32* gridBlocks, u32 numColors, u32 firstTail, bool serialBucket);
 void launch_solve_flow(World& w, u32 numManifolds, u32 itBegin, u32 itEnd, u32 firstColor);
+bool cluster_available(World& w);                          // sets up the cluster kernels' LDS budget once; false = this device cannot run them
+void launch_active_list(World& w, u32 numPairs);           // manifolds with contacts -> actIds (no colours)
+void launch_cluster_build(World& w, u32 numPairs);         // body order, tasks, local colouring, final slot order (k_cluster.hip)
+void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd);
 void launch_flow_regions(World& w, u32 numManifolds);       // region-major slot order for the XCD-local dataflow sweep
 u32 flow_num_regions(const World& w);
 void flow_choose_regions(World& w);

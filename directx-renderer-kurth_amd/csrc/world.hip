@@ -26,6 +26,7 @@ template <typename T> void DevBuf<T>::ensure(size_t n, hipStream_t s, bool keep)
 	size_t newCap = std::max(n, cap + cap / 2);
 	T* np = nullptr;
 	MI_CHECK(hipMalloc((void**)&np, newCap * sizeof(T)));
+	if (!np) return; // allocation failed: the world's error is set (MI_CHECK), the old buffer and capacity stay as they were
 	if (keep && p && cap) { MI_CHECK(hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, s)); MI_CHECK(hipStreamSynchronize(s)); }
 	if (p) MI_CHECK(hipFree(p));
 	p = np; cap = newCap;
@@ -47,19 +48,20 @@ World::World(int dev) : device(dev)
 	stageEvents.resize(STAGE_RING * 6);
 	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
 	useGraph = getenv("MI_PHYSICS_NO_GRAPH") == nullptr; // rocprofv3's kernel trace needs plain launches
-	useFlow = getenv("MI_PHYSICS_NO_FLOW") == nullptr;   // dataflow contact sweep (one launch) vs one launch per colour
-	useFlowRegions = getenv("MI_FLOW_REGIONS") != nullptr;
-	useFusedColoring = getenv("MI_PHYSICS_NO_FUSED_COLORING") == nullptr;
-	useSync2 = getenv("MI_PHYSICS_SYNC2") != nullptr;
+	useCluster = getenv("MI_PHYSICS_NO_CLUSTER") == nullptr; // LDS cluster contact sweep (one launch) vs global colouring + one launch per colour
+	useFusedColoring = false;                                // the launch sweep colours with one launch per round (no grid barrier)
 	useWarmColoring = getenv("MI_PHYSICS_NO_WARM_COLORING") == nullptr;
 	if (const char* e = getenv("MI_COLOR_FULL_INTERVAL")) fullColoringInterval = (u32)atoi(e);
-	if (const char* e = getenv("MI_FLOW_MAX")) flowMaxManifolds = (u32)atoi(e);
-	if (const char* e = getenv("MI_FLOW_EAGER")) flowEagerMax = (u32)atoi(e);
-	if (const char* e = getenv("MI_FLOW_TEST_ABORT")) flowTestAbortStep = (u32)atoi(e); // tests: make the dataflow sweep of that internal step give up
-	if (const char* e = getenv("MI_FLOW_HOP")) flowHopTicks = flowHopTicksLarge = (u32)atoi(e);
-	if (const char* e = getenv("MI_FLOW_HOP_LARGE")) flowHopTicksLarge = (u32)atoi(e);
-	if (const char* e = getenv("MI_FLOW_CAP")) flowBackoffCap = (u32)atoi(e);
-	if (const char* e = getenv("MI_FLOW_PREDICT")) flowPredictFrac = (u32)atoi(e);
+	if (const char* e = getenv("MI_FLOW_TEST_ABORT")) flowTestAbortStep = (u32)atoi(e); // tests: make the cluster sweep of that internal step give up
+	if (const char* e = getenv("MI_CLUSTER_PARTS")) clusterParts = std::min<u32>(CL_MAX_PARTS, std::max(1, atoi(e)));
+	if (const char* e = getenv("MI_CLUSTER_TASK")) clusterTaskWeight = 64u * (u32)std::max(16, atoi(e));   // manifolds per task
+	if (const char* e = getenv("MI_CLUSTER_SHIFT")) { int a = 0, b = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) for (u32 p = 1; p < CL_MAX_PARTS; ++p) { clusterShift[p][0] = (u32)a * p; clusterShift[p][1] = (u32)b * p; clusterShift[p][2] = (u32)c * p; } }
+	if (dCounters.p)
+	{
+		u32 box[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u }; // empty bounding box (k_cl_bbox accumulates, k_cl_offsets resets)
+		MI_CHECK(hipMemcpyAsync(dCounters.p + CTR_CL_BBOX, box, sizeof(box), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipStreamSynchronize(stream));
+	}
 }
 
 World::~World()
@@ -423,6 +425,7 @@ static void ensurePairBuffers(World& w, size_t numPairs)
 	w.manifolds.ensure(cap, w.stream); w.actIds.ensure(cap, w.stream); w.epaList.ensure(cap, w.stream); w.gjkSimplex.ensure(9 * cap, w.stream); w.mColor.ensure(cap, w.stream); w.mKey.ensure(cap, w.stream); w.mKeySorted.ensure(cap, w.stream); w.mIdx.ensure(cap, w.stream); w.mOrder.ensure(cap, w.stream);
 	w.rowPlanes.ensure((size_t)MI_MAX_CONTACTS_PER_MANIFOLD * MI_ROW_PLANES * cap, w.stream); w.rowShared.ensure(cap, w.stream);
 	w.rowLambda.ensure((size_t)MI_MAX_CONTACTS_PER_MANIFOLD * cap, w.stream); w.rowIds.ensure(cap, w.stream);
+	if (w.lastError) return; // an allocation failed: the capacities stay, the step returns the error
 	w.pairCap = cap; w.rowCap = cap; w.bufferVersion++;
 }
 
@@ -444,6 +447,8 @@ static void enqueueSolverSweep(World& w, u32 iters, const u32* gridBlocks, u32 n
 
 static const u32 TAIL_MAX_MANIFOLDS = 2048; // colours at the end of the schedule no larger than this go to the one-workgroup tail kernel
 
+// The launch-per-colour sweep (the fallback of the cluster sweep and the reference it is tested against): per iteration all joint
+// colours by type, then all contact colours, replayed as one hipGraph.
 static void runSolverSweep(World& w, u32 iters, u32 numColors)
 {
 	const u32* keyStart = w.hCounters + CTR_KEY_START;
@@ -462,35 +467,6 @@ static void runSolverSweep(World& w, u32 iters, u32 numColors)
 	u32 numJointKernels = 0;
 	for (auto& js : w.joints) numJointKernels += js.colorStart.empty() ? 0 : (u32)js.colorStart.size() - 1;
 	if (!numColors && !serial && !numJointKernels) return;
-
-	if (w.useFlow && numColors && !serial)
-	{
-		// Hybrid sweep.  The colours at the end of the schedule that together hold at most flowMaxManifolds manifolds (the long, thin
-		// tail of the greedy colouring: most of the colours, few of the manifolds) run in the dataflow kernel, where a colour step
-		// costs a hand-over (~2 us) instead of a launch (~5 us); the big colours in front keep their launches (a lane per manifold
-		// polling for its turn does not scale to 100k+ lanes: the sweep then advances at the pace of the slowest lane of every wave).
-		// If the whole schedule fits and there are no joints, all iterations run in ONE launch; otherwise one dataflow launch per
-		// iteration (joints are solved before the contacts in every iteration, constraints.cpp:3748-3772).
-		u32 numManifolds = w.hCounters[CTR_NUM_MANIFOLDS];
-		u32 firstFlow = numColors;
-		while (firstFlow > 0 && numManifolds - keyStart[4 * (firstFlow - 1)] <= w.flowMaxManifolds) --firstFlow;
-		if (firstFlow + 1 >= numColors && firstFlow > 0) firstFlow = numColors; // a one-colour tail is just a launch
-		if (firstFlow < numColors)
-		{
-			if (firstFlow == 0 && !numJointKernels)
-			{
-				launch_flow_regions(w, numManifolds);
-				launch_solve_flow(w, numManifolds, 0, iters, 0);
-			}
-			else for (u32 it = 0; it < iters; ++it)
-			{
-				launch_joint_solve_iteration(w);
-				if (firstFlow) launch_solve_contacts_iteration(w, need, firstFlow, firstFlow, false);
-				launch_solve_flow(w, numManifolds, it, it + 1, firstFlow);
-			}
-			return;
-		}
-	}
 
 	World::SolveGraph& g = w.solveGraph;
 	if (!w.useGraph)
@@ -520,24 +496,48 @@ static void runSolverSweep(World& w, u32 iters, u32 numColors)
 	if (g.exec) MI_CHECK(hipGraphLaunch(g.exec, w.stream));
 }
 
-// The dataflow sweep of the last step gave up (CTR_FLOW_STATUS != 0): its velocities are garbage and k_integrate_velocities skipped
-// itself.  hCounters still describes that step's schedule.  Restore the pre-solve velocities, clear the accumulated impulses and
-// run joints + contacts as launches, then integrate.  The dataflow stays off for a while.
+// Global colouring + rows + the launch sweep: the whole solver stage of a step on the fallback path.
+static void solveWithLaunchSweep(World& w, u32 numPairs, float dt, u32 iters)
+{
+	launch_coloring(w, numPairs);
+	launch_contact_init(w, numPairs, dt);
+	launch_joint_init(w, dt);
+	u32 numColors = 0;
+	if (numPairs)
+	{
+		readCounters(w);                                   // sync #2: colour boundaries of the contact schedule
+		numColors = w.hCounters[CTR_NUM_COLORS];
+		w.lastNumManifolds = w.hCounters[CTR_NUM_MANIFOLDS];
+		// adaptive colouring budget: last round that made progress + margin; grow quickly on overflow
+		u32 lastUseful = w.hCounters[CTR_LAST_ROUND];
+		w.coloringRounds = w.hCounters[CTR_OVERFLOW] ? std::min(1024u, w.coloringRounds * 2) : std::max(12u, lastUseful + 6);
+	}
+	else { memset(w.hCounters + CTR_KEY_START, 0, sizeof(u32) * (MI_NUM_SCHEDULE_KEYS + 1)); w.hCounters[CTR_NUM_MANIFOLDS] = 0; w.hCounters[CTR_NUM_VALID] = 0; w.lastNumManifolds = 0; }
+	runSolverSweep(w, iters, numColors);
+}
+
+// The cluster sweep of the last step gave up (CTR_FLOW_STATUS != 0: a task did not fit its tables or LDS, more tasks than
+// workgroups, or — only when the GPU is shared with another persistent kernel — a lane timed out waiting for a body): its
+// velocities are garbage and k_integrate_velocities skipped itself.  The manifolds of that step are still in place: restore the
+// pre-solve velocities, colour globally, rebuild the rows in that order, run joints + contacts as launches, integrate.  The
+// cluster sweep then stays off for a while.
 void World::recoverFlow()
 {
 	stats.numFlowRecoveries++;
-	flowCooldown = 256;
+	clusterCooldown = 256;
+	const size_t nb1 = (size_t)nb + 1;
 	MI_CHECK(hipMemsetAsync(dCounters.p + CTR_FLOW_STATUS, 0, sizeof(u32), stream));
-	MI_CHECK(hipMemcpyAsync(vel.p, velBackup.p, sizeof(float4) * 2 * ((size_t)nb + 1), hipMemcpyDeviceToDevice, stream));
-	if (rowCap) MI_CHECK(hipMemsetAsync(rowLambda.p, 0, sizeof(float2) * (size_t)MI_MAX_CONTACTS_PER_MANIFOLD * rowCap, stream));
-	launch_joint_init(*this, pendingDt);
-	bool flow = useFlow; useFlow = false;
-	runSolverSweep(*this, pendingIters, prevNumPairs ? hCounters[CTR_NUM_COLORS] : 0);
-	useFlow = flow;
+	MI_CHECK(hipMemsetAsync(dCounters.p + CTR_NUM_ACTIVE, 0, 2 * sizeof(u32), stream)); // active-list cursor + contact count: the list is rebuilt
+	MI_CHECK(hipMemcpyAsync(vel.p, velBackup.p, sizeof(float4) * 2 * nb1, hipMemcpyDeviceToDevice, stream));
+	MI_CHECK(hipMemsetAsync(bodyMask.p, 0, sizeof(u64) * nb1, stream));
+	MI_CHECK(hipMemsetAsync(claim.p, 0xFF, sizeof(u64) * 2 * nb1, stream));
+	forceFullColoring = true;
+	solveWithLaunchSweep(*this, prevNumPairs, pendingDt, pendingIters);
 	launch_integrate_velocities(*this, pendingDt);
+	lastStepCluster = false;
 }
 
-// Before the host looks at results: has the last step's dataflow sweep completed?  (One extra 4-byte read, only after a dataflow step.)
+// Before the host looks at results: has the last step's cluster sweep completed?  (One extra 4-byte read, only after a cluster step.)
 int World::resolvePendingFlow()
 {
 	if (!flowPending) return lastError;
@@ -547,7 +547,6 @@ int World::resolvePendingFlow()
 	MI_CHECK(hipStreamSynchronize(stream));
 	if (status)
 	{
-		readCounters(*this);
 		recoverFlow();
 		MI_CHECK(hipStreamSynchronize(stream));
 	}
@@ -614,28 +613,22 @@ int World::stepInternal(float dt, u32 iters)
 	launch_build_colliders(*this);
 	launch_broadphase_count(*this);
 	readCounters(*this);                                   // sync #1: number of overlapping pairs
-	if (hCounters[CTR_FLOW_STATUS])                        // a persistent kernel of the previous step gave up waiting
+	if (hCounters[CTR_FLOW_STATUS])                        // the cluster sweep of the previous step gave up
 	{
-		if (hCounters[CTR_FLOW_STATUS] & 8u) // the colouring barrier: the schedule itself is incomplete, nothing to redo it from
-		{
-			useFusedColoring = false;
-			fail(MI_ERR_HIP, "the fused colouring kernel gave up waiting at its grid barrier (GPU shared with another persistent kernel?); set MI_PHYSICS_NO_FUSED_COLORING=1");
-			return lastError;
-		}
 		flowPending = false;
-		recoverFlow();                                     // redo the previous step's solve + integration with the launch sweep
+		recoverFlow();                                     // redo the previous step's solve + integration with the launch sweep (synchronises)
 		launch_build_colliders(*this);                     // ... and this step's start, which ran on the stale poses
 		launch_broadphase_count(*this);
 		readCounters(*this);
 	}
 	flowPending = false;
 	countPreviousStep();                                   // the counters just read hold the previous step's colour / contact counts
-	u32 prevColors = stats.numInternalSteps ? stats.numColors : 0xFFFFu;
 	if (hCounters[CTR_TERRAIN_OVERFLOW]) { fail(MI_ERR_CAPACITY, "more terrain contacts than manifold slots: contacts were dropped (raise MI_TERRAIN_SLOTS_PER_COLLIDER)"); return lastError; }
 	const u32 truePairs = hCounters[CTR_NUM_PAIRS];
 	const u32 numPairs = truePairs + terrainSlotCap();     // bound on the manifold slots of the step: pair slots + room for the terrain contacts
 	ensurePairBuffers(*this, numPairs);
 	ensureEventBuffers(numPairs);
+	if (lastError) return lastError;                       // an allocation failed: nothing of this step may touch the pair buffers
 	launch_broadphase_write(*this, truePairs);
 	if (T) MI_CHECK(hipEventRecord(ev[1], stream));
 
@@ -644,57 +637,33 @@ int World::stepInternal(float dt, u32 iters)
 	launch_trigger_events(*this);                          // physics.cpp:1255 (handleNonCollisionInteractions)
 	if (T) MI_CHECK(hipEventRecord(ev[2], stream));
 
-	flow_choose_regions(*this);
 	launch_apply_fields(*this);                            // :963-967, :1273
-	if (useFlow) velBackup.ensure(2 * ((size_t)nb + 1), stream);
+	if (clusterCooldown) --clusterCooldown;
+	// Contact solver of this step: the LDS cluster sweep (one persistent launch, no host synchronisation: everything is sized on the
+	// device), or global colouring + one launch per colour when it is switched off, recovering, or cannot hold the turn counters.
+	const bool clusterStep = useCluster && !clusterCooldown && numPairs && iters && iters < 4096u && cluster_available(*this);
+	backupVelocities = clusterStep;                        // pre-solve velocities, in case the cluster sweep has to be redone (World::recoverFlow)
+	if (clusterStep) velBackup.ensure(2 * ((size_t)nb + 1), stream);
 	launch_integrate_forces(*this, dt);
 	launch_collision_events(*this, numPairs);              // :1284 (handleCollisionCallbacks: after the force integration)
-	launch_coloring(*this, numPairs);
-	launch_contact_init(*this, numPairs, dt);
-	launch_joint_init(*this, dt);
-	u32 numColors = 0;
-	if (flowCooldown) --flowCooldown;
-	// The dataflow sweep sizes itself on the device: the host only needs an estimate of the manifold count (last step's + 3 %; it
-	// decides between the one-manifold-per-lane build and the strided one, so it must not be generous; fewer lanes than manifolds is
-	// still correct, lanes then take several).  So the second synchronisation of the step is skipped
-	// while the colour count is comfortably below the 64-colour limit (the kernel checks the limit itself and gives up if it is hit:
-	// World::recoverFlow).  The launch sweep needs the colour table on the host and keeps the synchronisation.
-	bool noSync2 = useFlow && !flowCooldown && !useSync2 && numPairs && useFusedColoring && flow_num_regions(*this) == 1
-		&& prevColors + 8u < MI_MAX_COLORS && lastNumManifolds > 0;
-	if (noSync2)
+	if (clusterStep)
 	{
-		u32 est = std::min<u32>(numPairs, lastNumManifolds + lastNumManifolds / 32 + 512);
+		launch_cluster_build(*this, numPairs);
+		launch_contact_init(*this, numPairs, dt);
+		launch_joint_init(*this, dt);
 		if (T) MI_CHECK(hipEventRecord(ev[3], stream));
-		pendingDt = dt; pendingIters = iters; flowPending = true; // (the pre-solve velocities are in velBackup: k_integrate_forces)
+		pendingDt = dt; pendingIters = iters; flowPending = true; forceFullColoring = true;
 		u32 numJointKernels = 0;
 		for (auto& js : joints) numJointKernels += js.colorStart.empty() ? 0 : (u32)js.colorStart.size() - 1;
-		hCounters[CTR_KEY_START] = 0; // launch_solve_flow subtracts the first slot of its first colour: colour 0 starts at slot 0
-		if (!numJointKernels) launch_solve_flow(*this, est, 0, iters, 0);
-		else for (u32 it = 0; it < iters; ++it) { launch_joint_solve_iteration(*this); launch_solve_flow(*this, est, it, it + 1, 0); }
+		if (!numJointKernels) launch_cluster_solve(*this, 0, iters);
+		else for (u32 it = 0; it < iters; ++it) { launch_joint_solve_iteration(*this); launch_cluster_solve(*this, it, it + 1); } // joints before contacts in every iteration (constraints.cpp:3748-3772)
 	}
-	else if (numPairs)
+	else
 	{
-		readCounters(*this);                               // sync #2: colour boundaries of the contact schedule
-		numColors = hCounters[CTR_NUM_COLORS];
-		lastNumManifolds = hCounters[CTR_NUM_MANIFOLDS];
-		// adaptive colouring budget: last round that made progress + margin; grow quickly on overflow
-		u32 lastUseful = hCounters[CTR_LAST_ROUND];
-		coloringRounds = hCounters[CTR_OVERFLOW] ? std::min(1024u, coloringRounds * 2) : std::max(12u, lastUseful + 6);
+		solveWithLaunchSweep(*this, numPairs, dt, iters);
+		if (T) MI_CHECK(hipEventRecord(ev[3], stream)); // (the launch sweep is enqueued behind its own synchronisation: setup and solve are not separated here)
 	}
-	else { memset(hCounters + CTR_KEY_START, 0, sizeof(u32) * (MI_NUM_SCHEDULE_KEYS + 1)); hCounters[CTR_NUM_MANIFOLDS] = 0; hCounters[CTR_NUM_VALID] = 0; lastNumManifolds = 0; }
-	if (T && !noSync2) MI_CHECK(hipEventRecord(ev[3], stream));
-
-	bool flowStep = !noSync2 && useFlow && !flowCooldown && numPairs && numColors;
-	if (flowStep) // pre-solve velocities, in case the dataflow sweep has to be redone (World::recoverFlow)
-	{
-		pendingDt = dt; pendingIters = iters; flowPending = true;
-	}
-	if (!noSync2)
-	{
-		bool flow = useFlow; useFlow = flowStep;
-		runSolverSweep(*this, iters, numPairs ? numColors : 0);
-		useFlow = flow;
-	}
+	lastStepCluster = clusterStep;
 	if (T) MI_CHECK(hipEventRecord(ev[4], stream));
 
 	launch_integrate_velocities(*this, dt);
@@ -704,7 +673,7 @@ int World::stepInternal(float dt, u32 iters)
 	stats.numRigidBodies = nb; stats.numColliders = nc;
 	prevNumPairs = numPairs; prevTruePairs = truePairs;
 	stats.numInternalSteps++;
-	if (!noSync2) countPreviousStep(); // this step's counts are on the host already (hCounters comes from its own second read)
+	if (!clusterStep) countPreviousStep(); // this step's counts are on the host already (hCounters comes from its own second read)
 	u32 nj = 0; for (auto& js : joints) nj += (u32)js.order.size();
 	stats.numJoints = nj; stats.coloringRounds = coloringRounds;
 	return lastError;
@@ -1092,6 +1061,28 @@ mi_world* mi_world_restore(const mi_world_desc* desc, const void* buffer, uint64
 		w.cloths.push_back(std::move(c));
 	}
 	if (!in.ok) { g_createError = "mi_world_restore: truncated snapshot"; delete world; return nullptr; }
+	{ // every index the kernels will follow must point inside this world
+		bool valid = true;
+		const size_t numBodies = w.bodies.size(), numColliders = w.colliders.size(), numHulls = w.hulls.size();
+		for (const World::HBody& b : w.bodies) for (u32 c : b.colliders) if (c >= numColliders) valid = false;
+		for (const World::HCollider& c : w.colliders)
+		{
+			if (c.body != MI_STATIC_BODY && c.body >= numBodies) valid = false;
+			if (c.type > MI_HULL) valid = false;
+			if (c.type == MI_HULL && !(c.shape[7] >= 0.f && (size_t)c.shape[7] < numHulls)) valid = false;
+			if (c.zoneType == 2 && c.zoneIndex >= w.fields.size()) valid = false;
+			if (c.zoneType == 3 && c.zoneIndex >= w.triggers.size()) valid = false;
+		}
+		for (const World::HHull& h : w.hulls) { if (h.vertices.size() % 3 || h.triangles.size() % 3) valid = false; for (u32 t : h.triangles) if ((size_t)t * 3 + 2 >= h.vertices.size()) valid = false; }
+		for (u32 t = 0; t < MI_JOINT_TYPES; ++t)
+		{
+			const JointSet& js = w.joints[t];
+			size_t n = js.a.size();
+			if (js.b.size() != n || js.alive.size() != n || js.pods.size() != n * MI_JOINT_POD_SIZE[t]) { valid = false; continue; }
+			for (size_t i = 0; i < n; ++i) if (js.alive[i] && (js.a[i] >= numBodies || js.b[i] >= numBodies)) valid = false;
+		}
+		if (!valid) { g_createError = "mi_world_restore: snapshot holds an index outside the world"; delete world; return nullptr; }
+	}
 	w.clothsDirty = true;
 	w.collisionBeginEvents = (flags & 1u) != 0; w.collisionEndEvents = (flags & 2u) != 0;
 	w.topologyDirty = true; w.jointsDirty = true; w.fieldsDirty = true;
@@ -1466,6 +1457,13 @@ static void put3(float* o, V3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 
 static uint32_t pushJoint(World* w, u32 type, u32 a, u32 b, const void* pod)
 {
+	// both ends must be live rigid bodies of this world: the joint kernels index pose / vel with them (the reference ASSERTs the
+	// components exist, physics.cpp:128-140); MI_STATIC_BODY is not a joint end
+	if (a >= w->bodies.size() || b >= w->bodies.size() || w->bodies[a].removed || w->bodies[b].removed || !pod)
+	{
+		w->fail(MI_ERR_INVALID_ARGUMENT, "constraint: body out of range or deleted");
+		return 0xFFFFFFFFu;
+	}
 	JointSet& js = w->joints[type];
 	u32 sz = MI_JOINT_POD_SIZE[type];
 	js.pods.insert(js.pods.end(), (const uint8_t*)pod, (const uint8_t*)pod + sz);
@@ -1477,6 +1475,7 @@ static uint32_t pushJoint(World* w, u32 type, u32 a, u32 b, const void* pod)
 uint32_t mi_add_distance_constraint_local(mi_world* world, uint32_t a, uint32_t b, const float la[3], const float lb[3], float distance)
 {
 	CHECK_WORLD(0xFFFFFFFFu);
+	if (!la || !lb) { W->fail(MI_ERR_INVALID_ARGUMENT, "constraint: null anchor"); return 0xFFFFFFFFu; }
 	mi_distance_constraint c; memcpy(c.localAnchorA, la, 12); memcpy(c.localAnchorB, lb, 12); c.globalLength = distance;
 	return pushJoint(W, MI_CONSTRAINT_DISTANCE, a, b, &c);
 }
@@ -1490,6 +1489,7 @@ uint32_t mi_add_distance_constraint_global(mi_world* world, uint32_t a, uint32_t
 uint32_t mi_add_ball_constraint_local(mi_world* world, uint32_t a, uint32_t b, const float la[3], const float lb[3])
 {
 	CHECK_WORLD(0xFFFFFFFFu);
+	if (!la || !lb) { W->fail(MI_ERR_INVALID_ARGUMENT, "constraint: null anchor"); return 0xFFFFFFFFu; }
 	mi_ball_constraint c; memcpy(c.localAnchorA, la, 12); memcpy(c.localAnchorB, lb, 12);
 	return pushJoint(W, MI_CONSTRAINT_BALL, a, b, &c);
 }
@@ -1594,6 +1594,11 @@ int mi_delete_all_constraints_from_body(mi_world* world, uint32_t body)
 	return MI_OK;
 }
 
+// A setter that finds live state on the device while bodies / colliders were added since the last step cannot write to the device
+// (the buffers are about to be rebuilt) and must not write to the host mirror only (upload() would pull the device state over it):
+// pull the state now and let the host mirror be authoritative until upload().
+static void makeHostAuthoritative(World* w) { if (w->stateOnDevice && w->topologyDirty) { w->downloadState(); w->stateOnDevice = false; } }
+
 // Entity deletion (scene.deleteEntity -> the rigid body, its colliders and its constraints go away; collision_broad.cpp:42-75
 // removes the colliders from the sweep).  Body and collider indices are add-order positions and stay valid: the body is switched
 // off (no AABBs, no integration — the mechanism of the spatial slabs), its joints are deleted.
@@ -1602,6 +1607,7 @@ int mi_delete_body(mi_world* world, uint32_t body)
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
 	W->resolvePendingFlow();
+	makeHostAuthoritative(W);
 	int e = mi_delete_all_constraints_from_body(world, body);
 	if (e) return e;
 	{ World::HBody& hb = W->bodies[body]; hb.removed = true; hb.invMass = 0.f; for (int i = 0; i < 3; ++i) { hb.v[i] = 0.f; hb.w[i] = 0.f; } }
@@ -1778,6 +1784,7 @@ int mi_apply_force_torque(mi_world* world, uint32_t body, const float f[3], cons
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	W->resolvePendingFlow();
 	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
+	makeHostAuthoritative(W);
 	if (W->stateOnDevice && !W->topologyDirty && body < W->nb)
 	{
 		float4 cur[2];
@@ -1793,6 +1800,7 @@ int mi_set_velocity(mi_world* world, uint32_t body, const float lin[3], const fl
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	W->resolvePendingFlow();
 	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
+	makeHostAuthoritative(W);
 	World::HBody& b = W->bodies[body];
 	if (W->stateOnDevice && !W->topologyDirty && body < W->nb)
 	{
@@ -1807,6 +1815,7 @@ int mi_set_transform(mi_world* world, uint32_t body, const float pos[3], const f
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	W->resolvePendingFlow();
 	if (body >= W->bodies.size()) return MI_ERR_INVALID_ARGUMENT;
+	makeHostAuthoritative(W);
 	if (W->stateOnDevice && !W->topologyDirty && body < W->nb)
 	{
 		float4 p[2] = { make_float4(pos[0], pos[1], pos[2], 0.f), make_float4(rot[0], rot[1], rot[2], rot[3]) };
@@ -1920,15 +1929,6 @@ int mi_get_stats(mi_world* world, mi_stats* out)
 	W->refreshCounters();     // counts of the last step (one small read-back if the step did not do it itself)
 	W->harvestTiming();
 	mi_stats& st = W->stats;
-	if (W->useFlow && W->stats.numInternalSteps && W->dCounters.p)
-	{
-		// a step that read its counters back before the solve (the launch-per-round colouring path) has not seen its own poll count yet
-		u32 probes = 0;
-		W->resolvePendingFlow();
-		MI_CHECK(hipMemcpyAsync(&probes, W->dCounters.p + CTR_FLOW_PROBES, sizeof(u32), hipMemcpyDeviceToHost, W->stream));
-		MI_CHECK(hipStreamSynchronize(W->stream));
-		st.flowProbes = probes;
-	}
 	if (W->accTimed)
 	{
 		double n = W->accTimed;
@@ -2045,7 +2045,14 @@ int mi_debug_read_schedule(mi_world* world, uint32_t* outManifoldSlots, uint32_t
 	std::vector<uint4> ids(n);
 	d2h(W, ids.data(), W->rowIds.p, sizeof(uint4) * n); // rowIds[s].w = manifold slot executed at schedule position s
 	for (u32 s = 0; s < n; ++s) outManifoldSlots[s] = ids[s].w;
-	for (u32 c = 0; c <= MI_MAX_COLORS + 1; ++c) outColorStart[c] = W->hCounters[CTR_KEY_START + 4 * c];
+	if (W->lastStepCluster)
+	{
+		// The cluster sweep's order is (phase, task, local colour): there is no global colour table.  Report as many evenly sized
+		// "colours" as the largest local colouring has, so that callers who count colours see that number.
+		u32 nc = std::max(1u, W->hCounters[CTR_NUM_COLORS]);
+		for (u32 c = 0; c <= MI_MAX_COLORS + 1; ++c) outColorStart[c] = (c < nc) ? (u32)(((u64)n * c) / nc) : n;
+	}
+	else for (u32 c = 0; c <= MI_MAX_COLORS + 1; ++c) outColorStart[c] = W->hCounters[CTR_KEY_START + 4 * c];
 	return W->lastError;
 }
 int mi_debug_read_joint_order(mi_world* world, uint32_t type, uint32_t* out)
