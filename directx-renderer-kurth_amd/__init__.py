@@ -52,10 +52,11 @@ class Stats(C.Structure):
                 ("msCollidersBroad", C.c_float), ("msNarrow", C.c_float), ("msSolverSetup", C.c_float), ("msSolve", C.c_float),
                 ("msIntegrate", C.c_float), ("msTotal", C.c_float),
                 ("avgContacts", C.c_float), ("avgCollisions", C.c_float), ("avgColors", C.c_float), ("avgBroadphaseOverlaps", C.c_float), ("avgFlowProbes", C.c_float),
-                ("avgSteps", C.c_uint32)]
+                ("avgSteps", C.c_uint32),
+                ("clusterTasks", C.c_uint32 * 5), ("clusterManifolds", C.c_uint32 * 5), ("clusterSharedBodies", C.c_uint32), ("clusterParts", C.c_uint32)]
 
     def asdict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        return {n: (list(getattr(self, n)) if n in ("clusterTasks", "clusterManifolds") else getattr(self, n)) for n, _ in self._fields_}
 
 
 # mi_event (include/mi_physics.h): trigger_event / collision_begin_event / collision_end_event as one record

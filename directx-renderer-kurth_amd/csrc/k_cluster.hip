@@ -35,10 +35,11 @@ void prim_exclusive_scan_u32(World& w, const u32* in, u32* out, u32 n);
 #define CL_WEIGHT_MANIFOLD 64u            // weight of a manifold on the curve ...
 #define CL_WEIGHT_EXTRA 48u               // ... plus this per contact beyond the first (they cost LDS rows)
 #define CL_TASK_MAX_MANIFOLDS 2048u       // hard limits of k_cl_color's LDS tables (a task normally holds <= taskManifolds + one body's degree)
-#define CL_TASK_MAX_BODIES 2047u
-#define CL_HASH_SIZE 4096u
+#define CL_TASK_MAX_BODIES 4095u
+#define CL_HASH_SIZE 8192u
 #define CL_LOCAL_STATIC 0xFFFFu           // local body index of the static dummy body
 #define CL_SERIAL_COLOR 64u
+#define CL_REST_CAP 1024u                 // once no more than this many manifolds are unassigned, they all go to the rest task (it must fit k_cl_color's tables)
 #define CL_SPIN_LIMIT (1u << 22)          // polls before a lane gives up: only reached when the workgroups are not all resident
 
 MI_DEV u32 clOrderedBits(float f) { u32 b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
@@ -126,37 +127,50 @@ __global__ void __launch_bounds__(256) k_cl_weights0(const u32* __restrict__ cou
 }
 
 // Phase p: assign what is interior; what is left adds its weight to the next phase's curve, or (last partition) goes to the rest task.
-__global__ void __launch_bounds__(256) k_cl_assign(const u32* __restrict__ counters, u32 nb, u32 phase, u32 numParts, u32 taskWeight, const uint4* __restrict__ actIds,
+__global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 phase, u32 numParts, u32 taskWeight, const uint4* __restrict__ actIds,
 	const u32* __restrict__ rank, const u32* __restrict__ cum, const u32* __restrict__ rankNext, u32* __restrict__ wsumNext,
 	u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask, u32* __restrict__ status)
 {
 	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= counters[CTR_NUM_ACTIVE]) return;
-	if (taskKey[j] != CL_UNASSIGNED) return;
-	uint4 ids = actIds[j];
-	u32 a = ids.x, b = ids.y;
-	bool da = a < nb, db = b < nb;
-	u32 ta = da ? cum[rank[a]] / taskWeight : 0u, tb = db ? cum[rank[b]] / taskWeight : 0u;
-	if (!da) ta = tb;
-	if (!db) tb = ta;
+	const u32 entering = phase ? counters[CTR_CL_REMAIN + phase] : counters[CTR_NUM_ACTIVE];
+	const bool dumpAll = entering <= CL_REST_CAP; // few enough left: one task takes them all, later partitions stay empty
+	bool pending = j < counters[CTR_NUM_ACTIVE] && taskKey[j] == CL_UNASSIGNED;
 	u32 key = CL_UNASSIGNED;
-	if (ta == tb)
+	uint4 ids = make_uint4(0, 0, 0, 0);
+	bool da = false, db = false;
+	if (pending)
 	{
-		if (ta >= CL_MAX_TASKS) { atomicOr(status, 1u); ta = CL_MAX_TASKS - 1u; }
-		key = phase * CL_MAX_TASKS + ta;
+		ids = actIds[j];
+		da = ids.x < nb; db = ids.y < nb;
+		if (dumpAll) key = CL_MAX_PARTS * CL_MAX_TASKS;
+		else
+		{
+			u32 ta = da ? cum[rank[ids.x]] / taskWeight : 0u, tb = db ? cum[rank[ids.y]] / taskWeight : 0u;
+			if (!da) ta = tb;
+			if (!db) tb = ta;
+			if (ta == tb)
+			{
+				if (ta >= CL_MAX_TASKS) { atomicOr(status, 1u); ta = CL_MAX_TASKS - 1u; }
+				key = phase * CL_MAX_TASKS + ta;
+			}
+			else if (phase + 1u == numParts) key = CL_MAX_PARTS * CL_MAX_TASKS; // the rest task
+		}
 	}
-	else if (phase + 1u == numParts) key = numParts * CL_MAX_TASKS; // the rest task
+	bool left = pending && key == CL_UNASSIGNED;
+	u64 leftMask = __ballot(left);
+	if (leftMask && (threadIdx.x & 63u) == (u32)__ffsll((long long)leftMask) - 1u) atomicAdd(&counters[CTR_CL_REMAIN + phase + 1u], (u32)__popcll(leftMask));
+	if (!pending) return;
 	if (key != CL_UNASSIGNED)
 	{
 		u32 ph = key / CL_MAX_TASKS;
 		taskKey[j] = key;
 		taskPos[j] = atomicAdd(&taskCount[key], 1u);
-		if (da) atomicOr(&phaseMask[a], 1u << ph);
-		if (db) atomicOr(&phaseMask[b], 1u << ph);
+		if (da) atomicOr(&phaseMask[ids.x], 1u << ph);
+		if (db) atomicOr(&phaseMask[ids.y], 1u << ph);
 	}
 	else
 	{
-		u32 ra = rankNext[a], rb = rankNext[b];
+		u32 ra = rankNext[ids.x], rb = rankNext[ids.y];
 		atomicAdd(&wsumNext[min(ra, rb)], clWeight(ids.z));
 	}
 }
@@ -166,25 +180,26 @@ __global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters,
 {
 	__shared__ u32 part[1024];
 	__shared__ u32 lastTask[CL_MAX_PHASES];
-	const u32 total = CL_MAX_PHASES * CL_MAX_TASKS, per = total / 1024u;
+	const u32 total = CL_MAX_PHASES * CL_MAX_TASKS, per = (total + 1023u) / 1024u;
 	u32 t = threadIdx.x;
 	if (t < CL_MAX_PHASES) lastTask[t] = 0;
 	u32 sum = 0;
-	for (u32 k = 0; k < per; ++k) sum += taskCount[t * per + k];
+	for (u32 k = 0; k < per; ++k) if (t * per + k < total) sum += taskCount[t * per + k];
 	part[t] = sum;
 	__syncthreads();
 	for (u32 o = 1; o < 1024u; o <<= 1) { u32 v = (t >= o) ? part[t - o] : 0u; __syncthreads(); part[t] += v; __syncthreads(); }
 	u32 run = part[t] - sum;
 	for (u32 k = 0; k < per; ++k)
 	{
-		u32 key = t * per + k, c = taskCount[key];
+		u32 key = t * per + k;
+		if (key >= total) break;
+		u32 c = taskCount[key];
 		taskStart[key] = run; run += c;
 		if (c) atomicMax(&lastTask[key / CL_MAX_TASKS], (key % CL_MAX_TASKS) + 1u);
 	}
 	if (t == 1023u) taskStart[total] = run;
 	__syncthreads();
-	if (t <= numParts) counters[CTR_CL_NUM_TASKS + t] = lastTask[t];
-	else if (t < CL_MAX_PHASES) counters[CTR_CL_NUM_TASKS + t] = 0;
+	if (t < CL_MAX_PHASES) counters[CTR_CL_NUM_TASKS + t] = lastTask[t];
 	if (t == 0)
 	{
 		counters[CTR_NUM_MANIFOLDS] = part[1023];
@@ -217,7 +232,7 @@ struct ClTask
 static_assert(sizeof(ClTask) == 320, "task header");
 
 __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u32 nb, const u32* __restrict__ taskStart, const u32* __restrict__ pre, const uint4* __restrict__ actIds,
-	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ mExtra)
+	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ bodyUsers, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ mExtra, u32* __restrict__ mRank)
 {
 	extern __shared__ u32 clds[];
 	u32* hKey = clds;                                   // [CL_HASH_SIZE] global id + 1, 0 = empty
@@ -387,13 +402,44 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			if (tid == CL_LANES - 1u) T->numRows = n + waveBase + incl;
 		}
 		__syncthreads();
+		// 6. rank of every manifold among the users of each of its bodies, in position order (the dataflow sweep's turn numbers).
+		// Coloured manifolds: a colour occurs once per body, so the rank is the number of lower colours in the body's mask.  The serial
+		// tail (no colour left below 64: bodies with more than 64 users in this task) is walked by one lane in position order.
+		u32* inv = hKey;   // serial manifolds by position (the hash is no longer needed)
+		u32* rankL = hVal; // per manifold: rA | dA << 8 | rB << 16 | dB << 24 (d filled in below)
+		const u32 serialStart = hist[CL_SERIAL_COLOR * 4u - 1u]; // cursors have run: cursor of the last coloured class = first serial position
+		for (u32 l = tid; l < numBodies; l += CL_LANES) claim[l] = 0; // serial users per body
+		for (u32 i = tid; i < n; i += CL_LANES) if ((mKey[i] >> 2) >= CL_SERIAL_COLOR) inv[mPos[i] - serialStart] = i;
+		__syncthreads();
+		if (tid == 0)
+			for (u32 p = serialStart; p < n; ++p)
+			{
+				u32 i = inv[p - serialStart], ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16, r = 0;
+				if (la != CL_LOCAL_STATIC) { r |= ((u32)__popcll(mask[la]) + claim[la]) & 0xFFu; claim[la]++; }
+				if (lb != CL_LOCAL_STATIC) { r |= (((u32)__popcll(mask[lb]) + claim[lb]) & 0xFFu) << 16; claim[lb]++; }
+				rankL[i] = r;
+			}
+		__syncthreads();
+		bool tooBusy = false;
+		for (u32 l = tid; l < numBodies; l += CL_LANES)
+		{
+			u32 users = (u32)__popcll(mask[l]) + claim[l];
+			if (users > 250u) tooBusy = true; // the turn arithmetic keeps ranks and user counts in 8 bits
+			bodyUsers[(size_t)key * CL_BODY_STRIDE + l] = users;
+		}
+		if (tooBusy) atomicOr(&counters[CTR_CL_STATUS], 2u);
 		for (u32 i = tid; i < n; i += CL_LANES)
 		{
-			u32 p = mPos[i];
+			u32 p = mPos[i], ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16, c = mKey[i] >> 2;
+			u32 r = (c >= CL_SERIAL_COLOR) ? rankL[i] : 0u;
+			u64 lower = (c >= CL_SERIAL_COLOR) ? 0ull : ((1ull << c) - 1ull);
+			if (la != CL_LOCAL_STATIC) { if (c < CL_SERIAL_COLOR) r |= (u32)__popcll(mask[la] & lower); r |= ((((u32)__popcll(mask[la]) + claim[la])) & 0xFFu) << 8; }
+			if (lb != CL_LOCAL_STATIC) { if (c < CL_SERIAL_COLOR) r |= (u32)__popcll(mask[lb] & lower) << 16; r |= ((((u32)__popcll(mask[lb]) + claim[lb])) & 0xFFu) << 24; }
 			mOrder[first + p] = pre[first + i];
 			mKeySorted[first + p] = mKey[i];
-			mLocal[first + p] = mAB[i];
+			mLocal[first + p] = ab;
 			mExtra[first + p] = mCnt[p];
+			mRank[first + p] = r;
 		}
 		__syncthreads();
 	}
@@ -416,22 +462,29 @@ struct ClLocal // a task of this workgroup, in LDS
 	u32 colorStart[66];
 };
 
-// Row r of a task's LDS row region: 6 float4 planes + 1 float2 plane, plane-major (consecutive rows -> consecutive addresses).
+// Row r of a task's LDS row region: 8 float4 planes, plane-major (consecutive rows -> consecutive addresses); plane 7 = {mT, bias, lambdaN, lambdaT}.
 MI_DEV void clLoadRowLds(ContactRow& r, const float4* lds, u32 rowOff, u32 rowCap, u32 row)
 {
 	const float4* P = lds + rowOff + row;
-	r.p0 = P[0]; r.p1 = P[rowCap]; r.p2 = P[2 * rowCap]; r.p3 = P[3 * rowCap]; r.p4 = P[4 * rowCap]; r.p5 = P[5 * rowCap];
-	r.lam = ((const float2*)(lds + rowOff + 6 * rowCap))[row];
+	r.p0 = P[0]; r.p1 = P[rowCap]; r.p2 = P[2 * rowCap]; r.p3 = P[3 * rowCap]; r.p4 = P[4 * rowCap]; r.p5 = P[5 * rowCap]; r.p6 = P[6 * rowCap];
+	float4 q = P[7 * rowCap]; r.p7 = make_float2(q.x, q.y); r.lam = make_float2(q.z, q.w);
 }
-MI_DEV void clStoreLambdaLds(float4* lds, u32 rowOff, u32 rowCap, u32 row, float2 lam) { ((float2*)(lds + rowOff + 6 * rowCap))[row] = lam; }
+MI_DEV void clStoreRowLds(float4* lds, u32 rowOff, u32 rowCap, u32 row, const ContactRow& r)
+{
+	float4* P = lds + rowOff + row;
+	P[0] = r.p0; P[rowCap] = r.p1; P[2 * rowCap] = r.p2; P[3 * rowCap] = r.p3; P[4 * rowCap] = r.p4; P[5 * rowCap] = r.p5; P[6 * rowCap] = r.p6;
+	P[7 * rowCap] = make_float4(r.p7.x, r.p7.y, r.lam.x, r.lam.y);
+}
+MI_DEV void clStoreLambdaLds(float4* lds, u32 rowOff, u32 rowCap, u32 row, float2 lam) { ((float2*)(lds + rowOff + 7 * rowCap + row))[1] = lam; }
+MI_DEV float2 clLoadLambdaLds(const float4* lds, u32 rowOff, u32 rowCap, u32 row) { return ((const float2*)(lds + rowOff + 7 * rowCap + row))[1]; }
 
 struct ClArgs
 {
-	u32* counters; const ClTask* tasks; const u32* bodyList; const u32* phaseMask;
-	const u32* mKeySorted; const u32* mLocal; const u32* mExtra;
+	u32* counters; const ClTask* tasks; const u32* bodyList; const u32* bodyUsers; const u32* phaseMask;
+	const u32* mKeySorted; const u32* mLocal; const u32* mExtra; const u32* mRank;
 	const float4* rowPlanes; const float4* rowShared; float2* rowLambda;
-	float4* vel; u64* flow;
-	size_t rowCap; u32 nb, numParts, flowBytes, epoch, itBegin, itEnd, ldsFloat4s;
+	float4* vel; u64* flow; u64* trace; // trace: developer timeline (mi_debug_flow_trace), normally null
+	size_t rowCap; u32 nb, flowBytes, epoch, itBegin, itEnd, ldsFloat4s;
 };
 
 // One manifold: both bodies from LDS, its rows (registers / LDS / global memory), both bodies back.
@@ -470,6 +523,40 @@ template <bool REG> MI_DEV void clSolveManifold(float4* lds, const ClLocal& L, c
 	if (lb != CL_LOCAL_STATIC) { lds[L.bodyOff + 2 * lb] = make_float4(vB.x, vB.y, vB.z, invMassB); lds[L.bodyOff + 2 * lb + 1] = make_float4(wB.x, wB.y, wB.z, 0.f); }
 }
 
+// The same for a manifold of the register task, with everything address-like resolved beforehand: rd / wr are the float4 indices of
+// the two bodies (a static body reads the all-zero record and writes into a sink, so there is no branch around the LDS traffic),
+// rowOff / rowCap / slot come in registers instead of being re-read from the task record in LDS behind every barrier
+// (each such read is a dependent LDS round trip of ~100 cycles on the sweep's critical path).
+MI_DEV void clSolveReg(float4* lds, const ClArgs& A, u32 rdA, u32 wrA, u32 rdB, u32 wrB, u32 keyExtra, float4 sh, ContactRow& r0, u32 rowOff, u32 rowCap, u32 slot)
+{
+	float4 a0 = lds[rdA], a1 = lds[rdA + 1], b0 = lds[rdB], b1 = lds[rdB + 1];
+	V3 vA = v3f4(a0), wA = v3f4(a1), vB = v3f4(b0), wB = v3f4(b1);
+	float invMassA = a0.w, invMassB = b0.w;
+	V3 n = v3(sh.x, sh.y, sh.z);
+	float friction = sh.w;
+	solveRow(r0, n, friction, invMassA, invMassB, vA, wA, vB, wB);
+	u32 count = 4u - (keyExtra & 3u), extra = keyExtra >> 10;
+	for (u32 k = 1; k < count; ++k)
+	{
+		u32 row = extra + k - 1u;
+		ContactRow cur;
+		if (row < rowCap)
+		{
+			clLoadRowLds(cur, lds, rowOff, rowCap, row);
+			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
+			clStoreLambdaLds(lds, rowOff, rowCap, row, cur.lam);
+		}
+		else // beyond the LDS budget: streamed from global memory every iteration
+		{
+			loadRow(cur, k, slot, A.rowCap, A.rowPlanes, A.rowLambda);
+			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
+			A.rowLambda[(size_t)k * A.rowCap + slot] = cur.lam;
+		}
+	}
+	lds[wrA] = make_float4(vA.x, vA.y, vA.z, invMassA); lds[wrA + 1] = make_float4(wA.x, wA.y, wA.z, 0.f);
+	lds[wrB] = make_float4(vB.x, vB.y, vB.z, invMassB); lds[wrB + 1] = make_float4(wB.x, wB.y, wB.z, 0.f);
+}
+
 __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 {
 	extern __shared__ float4 lds[];
@@ -482,9 +569,10 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 	// ---- which tasks are mine, and where they live in LDS ----
 	if (tid == 0)
 	{
+		if (A.trace) A.trace[(size_t)blockIdx.x * 16u * 32u + 15 * 32] = wall_clock64();
 		u32 nT = 0, off = 0, used = 0; // used: float4s of LDS handed out
 		bool bad = A.counters[CTR_CL_STATUS] != 0u;
-		for (u32 p = 0; p <= A.numParts; ++p)
+		for (u32 p = 0; p < CL_MAX_PHASES; ++p)
 		{
 			u32 tasksInPhase = A.counters[CTR_CL_NUM_TASKS + p];
 			if (tasksInPhase > G) bad = true;
@@ -511,12 +599,12 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 		{
 			ClLocal& L = sTask[k];
 			u32 want = A.tasks[L.key].numRows - (L.inRegs ? L.count : 0u);
-			u32 left = (used + 1u < A.ldsFloat4s) ? A.ldsFloat4s - used - 1u : 0u; // one float4 stays free: the static dummy never needs it, keeps offsets in range
-			u32 fit = (u32)(((u64)left * 2u) / 13u);     // 6.5 float4 per row
+			u32 left = (used + 4u < A.ldsFloat4s) ? A.ldsFloat4s - used - 4u : 0u; // the last four float4 are the static body's all-zero record and the sink its writes go to
+			u32 fit = left / 8u;                          // 8 float4 per row
 			u32 cap = want < fit ? want : fit;
-			L.rowOff = used; L.rowCap = cap; used += (13u * cap + 1u) / 2u;
+			L.rowOff = used; L.rowCap = cap; used += 8u * cap;
 		}
-		if (used > A.ldsFloat4s) bad = true; // bodies + meta alone exceed LDS: cannot run this launch
+		if (used + 4u > A.ldsFloat4s) bad = true; // bodies + meta alone exceed LDS: cannot run this launch
 		if (bad) atomicOr(status, 64u);
 		sNumTasks = nT; sAbort = (bad || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1u : 0u;
 	}
@@ -557,9 +645,7 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 						if (row >= L.rowCap) continue; \
 						ContactRow cur; \
 						loadRow(cur, kk, slot, A.rowCap, A.rowPlanes, A.rowLambda); \
-						float4* P = lds + L.rowOff + row; \
-						P[0] = cur.p0; P[L.rowCap] = cur.p1; P[2 * L.rowCap] = cur.p2; P[3 * L.rowCap] = cur.p3; P[4 * L.rowCap] = cur.p4; P[5 * L.rowCap] = cur.p5; \
-						clStoreLambdaLds(lds, L.rowOff, L.rowCap, row, cur.lam); \
+						clStoreRowLds(lds, L.rowOff, L.rowCap, row, cur); \
 					} \
 				} \
 			}
@@ -579,13 +665,29 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 				if (row >= L.rowCap) continue;
 				ContactRow cur;
 				loadRow(cur, kk, slot, A.rowCap, A.rowPlanes, A.rowLambda);
-				float4* P = lds + L.rowOff + row;
-				P[0] = cur.p0; P[L.rowCap] = cur.p1; P[2 * L.rowCap] = cur.p2; P[3 * L.rowCap] = cur.p3; P[4 * L.rowCap] = cur.p4; P[5 * L.rowCap] = cur.p5;
-				clStoreLambdaLds(lds, L.rowOff, L.rowCap, row, cur.lam);
+				clStoreRowLds(lds, L.rowOff, L.rowCap, row, cur);
 			}
 		}
 	}
+	// the register task's bodies as LDS addresses (static body: read the zero record, write into the sink)
+	const u32 zeroRec = A.ldsFloat4s - 4u, sinkRec = A.ldsFloat4s - 2u;
+	if (tid < 2u) lds[zeroRec + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+	const u32 bodyOff0 = sTask[0].bodyOff;
+	const u32 rdA0 = (regAB0 & 0xFFFFu) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB0 & 0xFFFFu), wrA0 = (regAB0 & 0xFFFFu) == CL_LOCAL_STATIC ? sinkRec : rdA0;
+	const u32 rdB0 = (regAB0 >> 16) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB0 >> 16), wrB0 = (regAB0 >> 16) == CL_LOCAL_STATIC ? sinkRec : rdB0;
+	const u32 rdA1 = (regAB1 & 0xFFFFu) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB1 & 0xFFFFu), wrA1 = (regAB1 & 0xFFFFu) == CL_LOCAL_STATIC ? sinkRec : rdA1;
+	const u32 rdB1 = (regAB1 >> 16) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB1 >> 16), wrB1 = (regAB1 >> 16) == CL_LOCAL_STATIC ? sinkRec : rdB1;
+	const u32 rowOff0 = __builtin_amdgcn_readfirstlane(sTask[0].rowOff), rowCap0 = __builtin_amdgcn_readfirstlane(sTask[0].rowCap), first0 = __builtin_amdgcn_readfirstlane(sTask[0].first);
 	__syncthreads();
+	// developer timeline: 16 rows of 32 stamps per workgroup: row 3 k = "task k acquired its shared bodies" in iteration (column), row
+	// 3 k + 1 = "task k's colours done"; rows 5-6: core-clock stamp after every colour of iteration 10 of the first task, rows 7-8: the
+	// colours' sizes; row 15: [0] kernel start, [1] prologue done, [2 + 4 k ..] task k's size, colours, shared bodies, phase
+	u64* trace = A.trace ? A.trace + (size_t)blockIdx.x * 16u * 32u : nullptr;
+	if (trace && tid == 0)
+	{
+		trace[15 * 32 + 1] = wall_clock64();
+		for (u32 k = 0; k < numTasks; ++k) { trace[15 * 32 + 2 + 4 * k] = sTask[k].count; trace[15 * 32 + 3 + 4 * k] = sTask[k].numColors; trace[15 * 32 + 4 + 4 * k] = sTask[k].numShared; trace[15 * 32 + 5 + 4 * k] = sTask[k].phase | (sTask[k].numBodies << 8) | ((u64)sTask[k].rowCap << 32); }
+	}
 
 	// ---- iterations ----
 	bool aborted = false;
@@ -622,20 +724,25 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 			}
 			__syncthreads();
 			if (sAbort) { aborted = true; break; }
+			if (trace && tid == 0 && it - A.itBegin < 32u && k < 5u) trace[(3 * k) * 32 + (it - A.itBegin)] = wall_clock64();
 			// colours
 			if (L.inRegs)
 			{
 				const u32 col0 = (regKE0 & 0x3FFu) >> 2, col1 = (regKE1 & 0x3FFu) >> 2; // 255 = no manifold: matches no colour
-				for (u32 c = 0; c < L.numColors; ++c)
+				const u32 numColors = __builtin_amdgcn_readfirstlane(L.numColors), serialStart = __builtin_amdgcn_readfirstlane(L.serialStart), taskCount = __builtin_amdgcn_readfirstlane(L.count);
+				const bool stamp = trace && tid == 0 && it == A.itBegin + 10u && k == 0;
+				if (stamp) trace[5 * 32] = clock64();
+				for (u32 c = 0; c < numColors; ++c)
 				{
-					if (col0 == c) clSolveManifold<true>(lds, L, A, tid, regAB0, regKE0, regSh0, regRow0);
-					if (col1 == c) clSolveManifold<true>(lds, L, A, tid + CLS_LANES, regAB1, regKE1, regSh1, regRow1);
+					if (col0 == c) clSolveReg(lds, A, rdA0, wrA0, rdB0, wrB0, regKE0, regSh0, regRow0, rowOff0, rowCap0, first0 + tid);
+					if (col1 == c) clSolveReg(lds, A, rdA1, wrA1, rdB1, wrB1, regKE1, regSh1, regRow1, rowOff0, rowCap0, first0 + tid + CLS_LANES);
 					__syncthreads();
+					if (stamp) { trace[5 * 32 + 1 + c] = clock64(); trace[7 * 32 + c] = L.colorStart[c + 1] - L.colorStart[c]; }
 				}
-				for (u32 s = L.serialStart; s < L.count; ++s)
+				for (u32 sp = serialStart; sp < taskCount; ++sp)
 				{
-					if (tid == s) clSolveManifold<true>(lds, L, A, s, regAB0, regKE0, regSh0, regRow0);
-					if (tid + CLS_LANES == s) clSolveManifold<true>(lds, L, A, s, regAB1, regKE1, regSh1, regRow1);
+					if (tid == sp) clSolveReg(lds, A, rdA0, wrA0, rdB0, wrB0, regKE0, regSh0, regRow0, rowOff0, rowCap0, first0 + tid);
+					if (tid + CLS_LANES == sp) clSolveReg(lds, A, rdA1, wrA1, rdB1, wrB1, regKE1, regSh1, regRow1, rowOff0, rowCap0, first0 + tid + CLS_LANES);
 					__syncthreads();
 				}
 			}
@@ -660,6 +767,7 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 					__syncthreads();
 				}
 			}
+			if (trace && tid == 0 && it - A.itBegin < 32u && k < 5u && !(k == 1 && false)) trace[(3 * k + 1) * 32 + (it - A.itBegin)] = wall_clock64();
 			// hand the shared bodies on
 			for (u32 l = tid; l < L.numShared; l += CLS_LANES)
 			{
@@ -703,7 +811,7 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 					for (u32 kk = 1; kk < count; ++kk) \
 					{ \
 						u32 row = extra + kk - 1u; \
-						if (row < L.rowCap) A.rowLambda[(size_t)kk * A.rowCap + slot] = ((const float2*)(lds + L.rowOff + 6 * L.rowCap))[row]; \
+						if (row < L.rowCap) A.rowLambda[(size_t)kk * A.rowCap + slot] = clLoadLambdaLds(lds, L.rowOff, L.rowCap, row); \
 					} \
 				} \
 			}
@@ -719,7 +827,7 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 			for (u32 kk = 0; kk < count; ++kk)
 			{
 				u32 row = i + extra + kk;
-				if (row < L.rowCap) A.rowLambda[(size_t)kk * A.rowCap + slot] = ((const float2*)(lds + L.rowOff + 6 * L.rowCap))[row];
+				if (row < L.rowCap) A.rowLambda[(size_t)kk * A.rowCap + slot] = clLoadLambdaLds(lds, L.rowOff, L.rowCap, row);
 			}
 		}
 	}
@@ -762,10 +870,10 @@ void launch_cluster_build(World& w, u32 numPairs)
 	size_t nb1 = (size_t)nb + 1;
 	w.clKeys.ensure((size_t)P * nb, w.stream); w.clKeysSorted.ensure((size_t)P * nb, w.stream); w.clVals.ensure((size_t)P * nb, w.stream); w.clSorted.ensure((size_t)P * nb, w.stream);
 	w.clRank.ensure((size_t)P * nb1, w.stream); w.clWsum.ensure(2 * nb1, w.stream); w.clCum.ensure(nb1, w.stream); w.clPhaseMask.ensure(nb1, w.stream);
-	w.clTaskKey.ensure(w.pairCap, w.stream); w.clTaskPos.ensure(w.pairCap, w.stream); w.clPre.ensure(w.pairCap, w.stream); w.clLocal.ensure(w.pairCap, w.stream); w.clExtra.ensure(w.pairCap, w.stream);
+	w.clTaskKey.ensure(w.pairCap, w.stream); w.clTaskPos.ensure(w.pairCap, w.stream); w.clPre.ensure(w.pairCap, w.stream); w.clLocal.ensure(w.pairCap, w.stream); w.clExtra.ensure(w.pairCap, w.stream); w.clRankInfo.ensure(w.pairCap, w.stream);
 	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
 	w.clTaskCount.ensure(totalKeys, w.stream); w.clTaskStart.ensure(totalKeys + 1, w.stream);
-	w.clTasks.ensure((size_t)totalKeys * sizeof(ClTask), w.stream); w.clBodyList.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream);
+	w.clTasks.ensure((size_t)totalKeys * sizeof(ClTask), w.stream); w.clBodyList.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream); w.clBodyUsers.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream);
 	if (w.lastError) return;
 
 	dim3 bgrid((nb + 255) / 256), block(256), mgrid((numPairs + 255) / 256);
@@ -783,7 +891,8 @@ void launch_cluster_build(World& w, u32 numPairs)
 	MI_CHECK(hipMemsetAsync(w.clWsum.p, 0, sizeof(u32) * 2 * nb1, w.stream));
 	MI_CHECK(hipMemsetAsync(w.clPhaseMask.p, 0, sizeof(u32) * nb1, w.stream));
 	MI_CHECK(hipMemsetAsync(w.clTaskCount.p, 0, sizeof(u32) * totalKeys, w.stream));
-	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CL_STATUS, 0, sizeof(u32) * 8, w.stream)); // status, max colours, shared bodies, manifolds per phase
+	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CL_STATUS, 0, sizeof(u32) * 7, w.stream)); // status, shared bodies, manifolds per phase
+	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CL_REMAIN, 0, sizeof(u32) * 6, w.stream));
 	hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, w.clWsum.p, w.clTaskKey.p);
 	for (u32 p = 0; p < P; ++p)
 	{
@@ -796,7 +905,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, P, w.clTaskCount.p, w.clTaskStart.p);
 	hipLaunchKernelGGL(k_cl_scatter, mgrid, block, 0, w.stream, w.dCounters.p, w.clTaskKey.p, w.clTaskPos.p, w.clTaskStart.p, w.clPre.p);
 	hipLaunchKernelGGL(k_cl_color, dim3(w.clusterBlocks), dim3(CL_LANES), clColorLdsBytes(), w.stream, w.dCounters.p, nb, w.clTaskStart.p, w.clPre.p, w.actIds.p,
-		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clExtra.p);
+		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.clBodyUsers.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clExtra.p, w.clRankInfo.p);
 }
 
 // Iterations [itBegin, itEnd) of the contact sweep in one launch.
@@ -818,10 +927,10 @@ void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd)
 		MI_CHECK(hipStreamSynchronize(w.stream));
 	}
 	ClArgs A;
-	A.counters = w.dCounters.p; A.tasks = (const ClTask*)w.clTasks.p; A.bodyList = w.clBodyList.p; A.phaseMask = w.clPhaseMask.p;
-	A.mKeySorted = w.mKeySorted.p; A.mLocal = w.clLocal.p; A.mExtra = w.clExtra.p;
-	A.rowPlanes = w.rowPlanes.p; A.rowShared = w.rowShared.p; A.rowLambda = w.rowLambda.p; A.vel = w.vel.p; A.flow = w.flow.p;
-	A.rowCap = w.rowCap; A.nb = w.nb; A.numParts = w.clusterParts; A.flowBytes = (u32)(words * sizeof(u64)); A.epoch = w.flowEpoch << 16; A.itBegin = itBegin; A.itEnd = itEnd;
+	A.counters = w.dCounters.p; A.tasks = (const ClTask*)w.clTasks.p; A.bodyList = w.clBodyList.p; A.bodyUsers = w.clBodyUsers.p; A.phaseMask = w.clPhaseMask.p;
+	A.mKeySorted = w.mKeySorted.p; A.mLocal = w.clLocal.p; A.mExtra = w.clExtra.p; A.mRank = w.clRankInfo.p;
+	A.rowPlanes = w.rowPlanes.p; A.rowShared = w.rowShared.p; A.rowLambda = w.rowLambda.p; A.vel = w.vel.p; A.flow = w.flow.p; A.trace = w.flowTrace.p;
+	A.rowCap = w.rowCap; A.nb = w.nb; A.flowBytes = (u32)(words * sizeof(u64)); A.epoch = w.flowEpoch << 16; A.itBegin = itBegin; A.itEnd = itEnd;
 	A.ldsFloat4s = w.clusterLdsBytes / 16u;
 	hipLaunchKernelGGL(k_cl_solve, dim3(w.clusterBlocks), dim3(CLS_LANES), w.clusterLdsBytes, w.stream, A);
 }

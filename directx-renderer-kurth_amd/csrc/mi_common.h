@@ -198,7 +198,7 @@ struct ManifoldRec { float4 p[4]; float4 nf; uint4 ids; };
 //   vel[2i] = (v.xyz, invMass), vel[2i+1] = (w.xyz, 0).  Index numBodies is the zero-mass static dummy (never written).
 
 #define MI_MAX_CONTACTS_PER_MANIFOLD 4
-#define MI_ROW_PLANES 6          // read-only float4 planes per contact (24 floats)
+#define MI_ROW_PLANES 8          // read-only float4 planes per contact (30 floats; layout: solver_rows.h)
 #define MI_MAX_COLORS 64         // colours 0..63 run in parallel; colour 64 is the serial overflow bucket
 #define MI_SERIAL_COLOR 64
 

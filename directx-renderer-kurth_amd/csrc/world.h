@@ -87,18 +87,19 @@ enum
 	CTR_EVENT_OVERFLOW = 417,// bit 0: the event ring was full, events were dropped; bit 1: a pair-set table was full
 	CTR_TERRAIN_BASE = 418, // first manifold slot of the terrain contacts (= number of pair manifold slots)
 	CTR_TERRAIN_OVERFLOW = 419,// more terrain contacts than slots: contacts were dropped (the host fails the world)
-	CTR_CL_NUM_TASKS = 424, // 4 words: cluster sweep: tasks of phase p (positions up to the last non-empty one)
-	CTR_CL_STATUS = 428,    // cluster build: bit 0 = more tasks in a phase than the table holds, bit 1 = a task exceeds k_cl_color's tables
-	CTR_CL_SHARED = 429,    // statistics: bodies handed between tasks (summed over tasks)
-	CTR_CL_PHASE_COUNT = 430,// 4 words: statistics: manifolds per phase
+	CTR_CL_NUM_TASKS = 424, // 5 words: cluster sweep: tasks of phase p (positions up to the last non-empty one)
+	CTR_CL_STATUS = 429,    // cluster build: bit 0 = more tasks in a phase than the table holds, bit 1 = a task exceeds k_cl_color's tables
+	CTR_CL_SHARED = 430,    // statistics: bodies handed between tasks (summed over tasks)
+	CTR_CL_PHASE_COUNT = 431,// 5 words: statistics: manifolds per phase
 	CTR_CL_BBOX = 436,      // 6 words: min xyz, max xyz of the simulated bodies' centres of gravity (order-preserving integer encoding)
+	CTR_CL_REMAIN = 442,    // 6 words: manifolds still unassigned when partition phase p starts ([0] unused: all active ones)
 	CTR_WORDS = 512,
 };
 // Cluster sweep (k_cluster.hip): up to CL_MAX_PARTS partition phases + the rest phase; task key = phase * CL_MAX_TASKS + task.
-#define CL_MAX_PARTS 3u
+#define CL_MAX_PARTS 4u
 #define CL_MAX_PHASES (CL_MAX_PARTS + 1u)
 #define CL_MAX_TASKS 512u
-#define CL_BODY_STRIDE 2048u
+#define CL_BODY_STRIDE 4096u
 #define MI_NUM_SCHEDULE_KEYS ((MI_MAX_COLORS + 1) * 4)
 
 struct World
@@ -174,9 +175,10 @@ struct World
 	// cluster sweep (k_cluster.hip)
 	bool useCluster = true;               // MI_PHYSICS_NO_CLUSTER=1: launch-per-colour sweep only
 	bool lastStepCluster = false, backupVelocities = false;
-	u32 clusterParts = 2, clusterTaskWeight = 64u * 960u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
+	u32 clusterParts = 3, clusterTaskWeight = 64u * 960u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
+	bool clusterPartsFixed = false;       // MI_CLUSTER_PARTS given: no adaptation
 	u32 clusterLdsBytes = 0, clusterBlocks = 0, clusterCooldown = 0;
-	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clExtra, clTaskCount, clTaskStart, clBodyList;
+	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clExtra, clTaskCount, clTaskStart, clBodyList, clBodyUsers, clRankInfo;
 	DevBuf<uint8_t> clTasks;
 	DevBuf<u64> flowTrace;                // developer timeline (mi_debug_flow_trace): 32 x u64 per slot, allocated on request only
 	u32 flowEpoch = 0, flowMaxBlocks[2] = { 0, 0 };

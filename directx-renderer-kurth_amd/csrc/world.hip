@@ -53,7 +53,7 @@ World::World(int dev) : device(dev)
 	useWarmColoring = getenv("MI_PHYSICS_NO_WARM_COLORING") == nullptr;
 	if (const char* e = getenv("MI_COLOR_FULL_INTERVAL")) fullColoringInterval = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_TEST_ABORT")) flowTestAbortStep = (u32)atoi(e); // tests: make the cluster sweep of that internal step give up
-	if (const char* e = getenv("MI_CLUSTER_PARTS")) clusterParts = std::min<u32>(CL_MAX_PARTS, std::max(1, atoi(e)));
+	if (const char* e = getenv("MI_CLUSTER_PARTS")) { clusterParts = std::min<u32>(CL_MAX_PARTS, std::max(1, atoi(e))); clusterPartsFixed = true; }
 	if (const char* e = getenv("MI_CLUSTER_TASK")) clusterTaskWeight = 64u * (u32)std::max(16, atoi(e));   // manifolds per task
 	if (const char* e = getenv("MI_CLUSTER_SHIFT")) { int a = 0, b = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) for (u32 p = 1; p < CL_MAX_PARTS; ++p) { clusterShift[p][0] = (u32)a * p; clusterShift[p][1] = (u32)b * p; clusterShift[p][2] = (u32)c * p; } }
 	if (dCounters.p)
@@ -524,7 +524,17 @@ static void solveWithLaunchSweep(World& w, u32 numPairs, float dt, u32 iters)
 void World::recoverFlow()
 {
 	stats.numFlowRecoveries++;
-	clusterCooldown = 256;
+	// why: bit 6 = the cluster build did not fit (too many tasks in a phase, a task beyond the colouring tables or LDS): try again soon
+	// with one more partition phase; anything else = a lane timed out (GPU shared with another persistent kernel): stay away for a while
+	u32 why = hCounters[CTR_FLOW_STATUS];
+	if (getenv("MI_CLUSTER_DEBUG"))
+		fprintf(stderr, "[mi_physics] step %u: cluster sweep gave up: status %u, build status %u, parts %u, tasks %u %u %u %u %u, manifolds %u %u %u %u %u (active %u), remain %u %u %u %u %u\n", stats.numInternalSteps, why,
+			hCounters[CTR_CL_STATUS], clusterParts, hCounters[CTR_CL_NUM_TASKS], hCounters[CTR_CL_NUM_TASKS + 1], hCounters[CTR_CL_NUM_TASKS + 2], hCounters[CTR_CL_NUM_TASKS + 3], hCounters[CTR_CL_NUM_TASKS + 4],
+			hCounters[CTR_CL_PHASE_COUNT], hCounters[CTR_CL_PHASE_COUNT + 1], hCounters[CTR_CL_PHASE_COUNT + 2], hCounters[CTR_CL_PHASE_COUNT + 3], hCounters[CTR_CL_PHASE_COUNT + 4], hCounters[CTR_NUM_ACTIVE],
+			hCounters[CTR_CL_REMAIN + 1], hCounters[CTR_CL_REMAIN + 2], hCounters[CTR_CL_REMAIN + 3], hCounters[CTR_CL_REMAIN + 4], hCounters[CTR_CL_REMAIN + 5]);
+	if ((why & 64u) && !(why & 1u)) { clusterCooldown = 4; if (!clusterPartsFixed && clusterParts < CL_MAX_PARTS) ++clusterParts; }
+	else clusterCooldown = 256;
+	coloringRounds = 64;
 	const size_t nb1 = (size_t)nb + 1;
 	MI_CHECK(hipMemsetAsync(dCounters.p + CTR_FLOW_STATUS, 0, sizeof(u32), stream));
 	MI_CHECK(hipMemsetAsync(dCounters.p + CTR_NUM_ACTIVE, 0, 2 * sizeof(u32), stream)); // active-list cursor + contact count: the list is rebuilt
@@ -547,6 +557,7 @@ int World::resolvePendingFlow()
 	MI_CHECK(hipStreamSynchronize(stream));
 	if (status)
 	{
+		hCounters[CTR_FLOW_STATUS] = status;
 		recoverFlow();
 		MI_CHECK(hipStreamSynchronize(stream));
 	}
@@ -577,6 +588,19 @@ void World::countPreviousStep()
 	stats.numColors = had ? hCounters[CTR_NUM_COLORS] : 0; stats.flowProbes = hCounters[CTR_FLOW_PROBES];
 	stats.numBroadphaseOverlaps = prevTruePairs;
 	lastNumManifolds = stats.numCollisions;
+	for (u32 p = 0; p < 5; ++p)
+	{
+		stats.clusterTasks[p] = (had && lastStepCluster) ? hCounters[CTR_CL_NUM_TASKS + p] : 0;
+		stats.clusterManifolds[p] = (had && lastStepCluster) ? hCounters[CTR_CL_PHASE_COUNT + p] : 0;
+	}
+	stats.clusterSharedBodies = (had && lastStepCluster) ? hCounters[CTR_CL_SHARED] : 0; stats.clusterParts = lastStepCluster ? clusterParts : 0;
+	// Partition phases of the next step: one more when the rest task is filling up (it has hard limits), one fewer when the last
+	// one found nothing to do (each costs a sort of the bodies).
+	if (had && lastStepCluster && !clusterPartsFixed)
+	{
+		if (hCounters[CTR_CL_PHASE_COUNT + CL_MAX_PARTS] > 768u && clusterParts < CL_MAX_PARTS) ++clusterParts;
+		else if (clusterParts > 1 && hCounters[CTR_CL_PHASE_COUNT + clusterParts - 1] == 0 && hCounters[CTR_CL_REMAIN + clusterParts - 1] < 384u) --clusterParts;
+	}
 	sumContacts += stats.numContacts; sumManifolds += stats.numCollisions; sumColors += stats.numColors; sumPairs += prevTruePairs; sumProbes += stats.flowProbes; sumSteps++;
 }
 

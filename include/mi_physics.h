@@ -62,11 +62,14 @@ typedef struct mi_stats
 	uint32_t numRigidBodies, numColliders, numBroadphaseOverlaps, numCollisions, numContacts;
 	uint32_t numColors, numJoints, numInternalSteps;
 	uint32_t numGraphBuilds, coloringRounds; /* solver-sweep hipGraph (re)builds so far; colouring round budget of the last step */
-	uint32_t flowProbes;                     /* dataflow contact sweep: body-record polls of the step before the last one (0 = launch sweep) */
-	uint32_t numFlowRecoveries;              /* steps whose dataflow sweep gave up and was redone with the launch sweep (should stay 0) */
+	uint32_t flowProbes;                     /* unused (kept for layout compatibility) */
+	uint32_t numFlowRecoveries;              /* steps whose cluster contact sweep gave up and was redone with the launch sweep (should stay 0) */
 	float msCollidersBroad, msNarrow, msSolverSetup, msSolve, msIntegrate, msTotal; /* HIP-event times, mean over the timed steps since the previous mi_get_stats (timing enabled only) */
 	float avgContacts, avgCollisions, avgColors, avgBroadphaseOverlaps, avgFlowProbes; /* means over the internal steps since the previous mi_get_stats */
 	uint32_t avgSteps;                                                                 /* ... and how many steps that was */
+	/* cluster contact sweep of the last step (all 0 after a launch-sweep step): tasks and manifolds per phase ([4] = the rest task),
+	 * bodies handed between tasks (summed over the tasks that touch them), partition phases prepared */
+	uint32_t clusterTasks[5], clusterManifolds[5], clusterSharedBodies, clusterParts;
 } mi_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------ */

@@ -154,6 +154,7 @@ struct collision_constraint
 	vec3 tangentImpulseToAngularVelocityA, tangentImpulseToAngularVelocityB;
 	vec3 normalImpulseToAngularVelocityA, normalImpulseToAngularVelocityB;
 	float impulseInNormalDir, impulseInTangentDir, effectiveMassInNormalDir, effectiveMassInTangentDir, bias;
+	vec3 crAt, crBt, crAn, crBn; // rA x tangent, rB x tangent, rA x normal, rB x normal: the angular parts of the row Jacobians (kept for the row-form solve)
 };
 
 static inline void initializeCollisionConstraint(collision_constraint& constraint, const rigid_body_global_state* rbs, const collision_contact& contact, constraint_body_pair pair, float dt)
@@ -177,6 +178,7 @@ static inline void initializeCollisionConstraint(collision_constraint& constrain
 		constraint.effectiveMassInTangentDir = (invMassInTangentDir != 0.f) ? (1.f / invMassInTangentDir) : 0.f;
 		constraint.tangentImpulseToAngularVelocityA = rbA.invInertia * crAt;
 		constraint.tangentImpulseToAngularVelocityB = rbB.invInertia * crBt;
+		constraint.crAt = crAt; constraint.crBt = crBt;
 	}
 	{
 		vec3 crAn = cross(constraint.relGlobalAnchorA, contact.normal);
@@ -196,6 +198,7 @@ static inline void initializeCollisionConstraint(collision_constraint& constrain
 		}
 		constraint.normalImpulseToAngularVelocityA = rbA.invInertia * crAn;
 		constraint.normalImpulseToAngularVelocityB = rbB.invInertia * crBn;
+		constraint.crAn = crAn; constraint.crBn = crBn;
 	}
 }
 
@@ -238,6 +241,56 @@ static inline void solveCollisionConstraint(collision_constraint& constraint, co
 		wA -= constraint.normalImpulseToAngularVelocityA * lambda;
 		vB += rbB.invMass * P;
 		wB += constraint.normalImpulseToAngularVelocityB * lambda;
+	}
+	rbA.linearVelocity = vA; rbA.angularVelocity = wA;
+	rbB.linearVelocity = vB; rbB.angularVelocity = wB;
+}
+
+// The same contact in ROW FORM, as the device evaluates it (directx-renderer-kurth_amd/csrc/solver_rows.h): the relative anchor velocity
+// projected on the row direction d, dot((vB + wB x rB) - (vA + wA x rA), d), is written with the scalar triple product as
+// d . (vB - vA) + (rB x d) . wB - (rA x d) . wA and evaluated with fused multiply-adds in the association of the reference's wide
+// dot (fmadd(a.x, b.x, fmadd(a.y, b.y, a.z * b.z)), core/math_simd.h:241); the impulse is applied as v -+= (invMass * lambda) * d,
+// w -+= J * lambda, one fma per component.  Same mathematics as solveCollisionConstraint above, different rounding: this is the
+// function the device is compared with bit for bit; tests/test_oracle.py bounds its distance from the reference formula.
+static inline float rowVelocity(vec3 d, vec3 cA, vec3 cB, vec3 vA, vec3 wA, vec3 vB, vec3 wB)
+{
+	vec3 dv = vB - vA;
+	float s = dv.z * d.z;
+	s = __builtin_fmaf(dv.y, d.y, s); s = __builtin_fmaf(dv.x, d.x, s);
+	s = __builtin_fmaf(wB.z, cB.z, s); s = __builtin_fmaf(wB.y, cB.y, s); s = __builtin_fmaf(wB.x, cB.x, s);
+	s = __builtin_fmaf(-wA.z, cA.z, s); s = __builtin_fmaf(-wA.y, cA.y, s); s = __builtin_fmaf(-wA.x, cA.x, s);
+	return s;
+}
+static inline void rowApply(float lambda, vec3 d, vec3 JA, vec3 JB, float invMassA, float invMassB, vec3& vA, vec3& wA, vec3& vB, vec3& wB)
+{
+	float a = invMassA * lambda, b = invMassB * lambda;
+	vA = vec3(__builtin_fmaf(-a, d.x, vA.x), __builtin_fmaf(-a, d.y, vA.y), __builtin_fmaf(-a, d.z, vA.z));
+	vB = vec3(__builtin_fmaf(b, d.x, vB.x), __builtin_fmaf(b, d.y, vB.y), __builtin_fmaf(b, d.z, vB.z));
+	wA = vec3(__builtin_fmaf(-lambda, JA.x, wA.x), __builtin_fmaf(-lambda, JA.y, wA.y), __builtin_fmaf(-lambda, JA.z, wA.z));
+	wB = vec3(__builtin_fmaf(lambda, JB.x, wB.x), __builtin_fmaf(lambda, JB.y, wB.y), __builtin_fmaf(lambda, JB.z, wB.z));
+}
+static inline void solveCollisionConstraintRowForm(collision_constraint& constraint, const collision_contact& contact, constraint_body_pair pair, rigid_body_global_state* rbs)
+{
+	rigid_body_global_state& rbA = rbs[pair.rbA];
+	rigid_body_global_state& rbB = rbs[pair.rbB];
+	vec3 vA = rbA.linearVelocity, wA = rbA.angularVelocity, vB = rbB.linearVelocity, wB = rbB.angularVelocity;
+	{
+		float vt = rowVelocity(constraint.tangent, constraint.crAt, constraint.crBt, vA, wA, vB, wB);
+		float lambda = -constraint.effectiveMassInTangentDir * vt;
+		float friction = (float)(contact.friction_restitution >> 16) / (float)0xFFFF;
+		float maxFriction = friction * constraint.impulseInNormalDir;
+		float newImpulse = clampf(constraint.impulseInTangentDir + lambda, -maxFriction, maxFriction);
+		lambda = newImpulse - constraint.impulseInTangentDir;
+		constraint.impulseInTangentDir = newImpulse;
+		rowApply(lambda, constraint.tangent, constraint.tangentImpulseToAngularVelocityA, constraint.tangentImpulseToAngularVelocityB, rbA.invMass, rbB.invMass, vA, wA, vB, wB);
+	}
+	{
+		float vn = rowVelocity(contact.normal, constraint.crAn, constraint.crBn, vA, wA, vB, wB);
+		float lambda = -constraint.effectiveMassInNormalDir * (vn - constraint.bias);
+		float impulse = std::max(constraint.impulseInNormalDir + lambda, 0.f);
+		lambda = impulse - constraint.impulseInNormalDir;
+		constraint.impulseInNormalDir = impulse;
+		rowApply(lambda, contact.normal, constraint.normalImpulseToAngularVelocityA, constraint.normalImpulseToAngularVelocityB, rbA.invMass, rbB.invMass, vA, wA, vB, wB);
 	}
 	rbA.linearVelocity = vA; rbA.angularVelocity = wA;
 	rbB.linearVelocity = vB; rbB.angularVelocity = wB;

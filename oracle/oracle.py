@@ -282,6 +282,10 @@ class OracleWorld:
         self._follow_keep = (pairs, order)
         self.lib.orc_set_follow(self.w, _p(pairs), C.c_uint32(len(pairs)), _p(order), C.c_uint32(len(order)))
 
+    def set_row_form(self, on=True):
+        """Custom-order contact solves in the device's row form (default) or with the reference formula."""
+        self.lib.orc_set_row_form(self.w, int(on))
+
     def clear_follow(self):
         self.lib.orc_clear_follow(self.w)
 

@@ -112,6 +112,7 @@ struct world
 
 	// Optional external GS order for contacts: a permutation (or subset order) of contact indices.
 	std::vector<u32> customOrder;
+	bool rowForm = true; // custom-order solves use the device's row form (solveCollisionConstraintRowForm); false = the reference formula
 	// "Follow" mode for whole-step parity with a device run: the narrowphase consumes an externally ordered candidate-pair list
 	// (slots) instead of prune/classify/bucket, contacts are solved manifold by manifold in `slotOrder`, joints in `jointOrder[t]`.
 	bool usePairOverride = false;
@@ -876,7 +877,8 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 		if (mode == solver_wide8) { solveCollisionBatchesWide(batches, rbs); }
 		else if (mode == solver_custom_order)
 		{
-			for (u32 ci : w.customOrder) { if (ci < numContacts) solveCollisionConstraint(w.contactConstraints[ci], w.contacts[ci], w.contactBodyPairs[ci], rbs); }
+			if (w.rowForm) { for (u32 ci : w.customOrder) { if (ci < numContacts) solveCollisionConstraintRowForm(w.contactConstraints[ci], w.contacts[ci], w.contactBodyPairs[ci], rbs); } }
+			else for (u32 ci : w.customOrder) { if (ci < numContacts) solveCollisionConstraint(w.contactConstraints[ci], w.contacts[ci], w.contactBodyPairs[ci], rbs); }
 		}
 		else
 		{
@@ -1440,6 +1442,7 @@ int orc_set_velocity(world* w, u32 b, const float* lin, const float* ang)
 int orc_step(world* w, float* timer, const physics_settings* settings, u32 mode, float dt) { physicsStep(*w, *timer, *settings, mode, dt); return 0; }
 int orc_step_internal(world* w, u32 iterations, u32 mode, float dt) { physicsStepInternal(*w, iterations, mode, dt); return 0; }
 void orc_set_custom_order(world* w, const u32* order, u32 n) { w->customOrder.assign(order, order + n); }
+void orc_set_row_form(world* w, int on) { w->rowForm = on != 0; }
 // Follow mode (see struct world): ordered candidate pairs + manifold execution order; n = 0 switches it off.
 void orc_set_follow(world* w, const u32* pairs2, u32 numPairs, const u32* slotOrder, u32 numOrder)
 {
