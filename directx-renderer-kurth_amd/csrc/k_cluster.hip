@@ -63,8 +63,15 @@ __global__ void __launch_bounds__(256) k_cl_bbox(u32 nb, const float4* __restric
 	}
 	for (int k = 0; k < 3; ++k)
 		for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
-	if ((threadIdx.x & 63u) == 0u && mn[0] <= mx[0])
-		for (int k = 0; k < 3; ++k) { atomicMin(&counters[CTR_CL_BBOX + k], clOrderedBits(mn[k])); atomicMax(&counters[CTR_CL_BBOX + 3 + k], clOrderedBits(mx[k])); }
+	__shared__ float sMn[4][3], sMx[4][3]; // one atomic pair per workgroup and axis: same-address atomics from all over the chip serialise
+	if ((threadIdx.x & 63u) == 0u) for (int k = 0; k < 3; ++k) { sMn[threadIdx.x >> 6][k] = mn[k]; sMx[threadIdx.x >> 6][k] = mx[k]; }
+	__syncthreads();
+	if (threadIdx.x < 3u)
+	{
+		u32 k = threadIdx.x;
+		float a = fminf(fminf(sMn[0][k], sMn[1][k]), fminf(sMn[2][k], sMn[3][k])), b = fmaxf(fmaxf(sMx[0][k], sMx[1][k]), fmaxf(sMx[2][k], sMx[3][k]));
+		if (a <= b) { atomicMin(&counters[CTR_CL_BBOX + k], clOrderedBits(a)); atomicMax(&counters[CTR_CL_BBOX + 3 + k], clOrderedBits(b)); }
+	}
 }
 
 struct ClShifts { u32 s[CL_MAX_PARTS][3]; };
@@ -113,6 +120,19 @@ __global__ void __launch_bounds__(256) k_cl_ranks(u32 nb, u32 numParts, const u3
 // (20 % of a mixed pile) out of most colours.  Then a pseudo-random priority (hash of the narrowphase slot and the round), then
 // the position inside the task, which makes the bid unique.
 MI_DEV u32 clBid(u32 slot, u32 count, u32 round, u32 i) { return ((4u - count) << 30) | ((clHash(slot * 2654435761u + round) & 0x3FFFFu) << 12) | i; }
+#define CL_SUBCOUNTERS 8u // a task's append cursor is split in 8 (by workgroup) so that ~650 returning atomics do not queue on one address
+
+// Everything the assignment accumulates into, cleared in one launch.
+__global__ void __launch_bounds__(256) k_cl_clear(u32 nb1, u32* __restrict__ wsum, u32* __restrict__ phaseMask, u32* __restrict__ taskCount, u32* __restrict__ counters)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < CL_MAX_PARTS * nb1) wsum[i] = 0;
+	if (i < nb1) phaseMask[i] = 0;
+	if (i < CL_MAX_PHASES * CL_MAX_TASKS * CL_SUBCOUNTERS) taskCount[i] = 0;
+	if (i < 7u) counters[CTR_CL_STATUS + i] = 0;  // status, shared bodies, manifolds per phase
+	if (i < 6u) counters[CTR_CL_REMAIN + i] = 0;
+}
+
 MI_DEV u32 clWeight(u32 count) { return CL_WEIGHT_MANIFOLD + (count - 1u) * CL_WEIGHT_EXTRA; }
 
 __global__ void __launch_bounds__(256) k_cl_weights0(const u32* __restrict__ counters, u32 nb, const uint4* __restrict__ actIds, const u32* __restrict__ rank0,
@@ -157,14 +177,14 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 		}
 	}
 	bool left = pending && key == CL_UNASSIGNED;
-	u64 leftMask = __ballot(left);
-	if (leftMask && (threadIdx.x & 63u) == (u32)__ffsll((long long)leftMask) - 1u) atomicAdd(&counters[CTR_CL_REMAIN + phase + 1u], (u32)__popcll(leftMask));
+	u32 numLeft = (u32)__syncthreads_count(left); // one atomic per workgroup
+	if (threadIdx.x == 0 && numLeft) atomicAdd(&counters[CTR_CL_REMAIN + phase + 1u], numLeft);
 	if (!pending) return;
 	if (key != CL_UNASSIGNED)
 	{
 		u32 ph = key / CL_MAX_TASKS;
 		taskKey[j] = key;
-		taskPos[j] = atomicAdd(&taskCount[key], 1u);
+		taskPos[j] = atomicAdd(&taskCount[key * CL_SUBCOUNTERS + (blockIdx.x & (CL_SUBCOUNTERS - 1u))], 1u);
 		if (da) atomicOr(&phaseMask[ids.x], 1u << ph);
 		if (db) atomicOr(&phaseMask[ids.y], 1u << ph);
 	}
@@ -180,7 +200,7 @@ __global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters,
 {
 	__shared__ u32 part[1024];
 	__shared__ u32 lastTask[CL_MAX_PHASES];
-	const u32 total = CL_MAX_PHASES * CL_MAX_TASKS, per = (total + 1023u) / 1024u;
+	const u32 total = CL_MAX_PHASES * CL_MAX_TASKS * CL_SUBCOUNTERS, per = (total + 1023u) / 1024u;
 	u32 t = threadIdx.x;
 	if (t < CL_MAX_PHASES) lastTask[t] = 0;
 	u32 sum = 0;
@@ -191,10 +211,10 @@ __global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters,
 	u32 run = part[t] - sum;
 	for (u32 k = 0; k < per; ++k)
 	{
-		u32 key = t * per + k;
-		if (key >= total) break;
-		u32 c = taskCount[key];
-		taskStart[key] = run; run += c;
+		u32 e = t * per + k;
+		if (e >= total) break;
+		u32 c = taskCount[e], key = e / CL_SUBCOUNTERS;
+		taskStart[e] = run; run += c;
 		if (c) atomicMax(&lastTask[key / CL_MAX_TASKS], (key % CL_MAX_TASKS) + 1u);
 	}
 	if (t == 1023u) taskStart[total] = run;
@@ -210,9 +230,9 @@ __global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters,
 
 __global__ void __launch_bounds__(256) k_cl_scatter(const u32* __restrict__ counters, const u32* __restrict__ taskKey, const u32* __restrict__ taskPos, const u32* __restrict__ taskStart, u32* __restrict__ pre)
 {
-	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+	u32 j = blockIdx.x * blockDim.x + threadIdx.x; // same launch geometry as k_cl_assign: blockIdx selects the same sub-counter
 	if (j >= counters[CTR_NUM_ACTIVE]) return;
-	pre[taskStart[taskKey[j]] + taskPos[j]] = j;
+	pre[taskStart[taskKey[j] * CL_SUBCOUNTERS + (blockIdx.x & (CL_SUBCOUNTERS - 1u))] + taskPos[j]] = j;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -226,13 +246,13 @@ __global__ void __launch_bounds__(256) k_cl_scatter(const u32* __restrict__ coun
 // ---------------------------------------------------------------------------------------------------------------
 struct ClTask
 {
-	u32 first, count, numBodies, numShared, numColors, serialStart, numRows, pad;
+	u32 first, count, numBodies, numShared, numColors, serialStart, numRows, sharedBase; // sharedBase: first hand-over record of the task's shared bodies
 	u32 colorStart[72]; // position (relative to first) of the first manifold of colour c; [numColors] = serialStart
 };
 static_assert(sizeof(ClTask) == 320, "task header");
 
 __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u32 nb, const u32* __restrict__ taskStart, const u32* __restrict__ pre, const uint4* __restrict__ actIds,
-	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ bodyUsers, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ mExtra, u32* __restrict__ mRank)
+	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ bodyUsers, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ mExtra, u32* __restrict__ mRank, u32* __restrict__ sharedSlot)
 {
 	extern __shared__ u32 clds[];
 	u32* hKey = clds;                                   // [CL_HASH_SIZE] global id + 1, 0 = empty
@@ -243,14 +263,15 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 	u32* mKey = mAB + CL_TASK_MAX_MANIFOLDS;            // [..] colour * 4 + (4 - count); UNCOLORED while colouring
 	u32* mPos = mKey + CL_TASK_MAX_MANIFOLDS;           // [..] final position
 	u32* mCnt = mPos + CL_TASK_MAX_MANIFOLDS;           // [..] contact count by final position, then its exclusive scan of (count - 1)
-	u32* hist = mCnt + CL_TASK_MAX_MANIFOLDS;           // [264] per key, then cursors
-	__shared__ u32 sNumShared, sNumPrivate, sLeft, sMaxColor, sScan[16];
+	u32* mSlot = mCnt + CL_TASK_MAX_MANIFOLDS;          // [..] narrowphase slot | contacts << 28 (the colouring rounds' priorities hash it)
+	u32* hist = mSlot + CL_TASK_MAX_MANIFOLDS;          // [264] per key, then cursors
+	__shared__ u32 sNumShared, sNumPrivate, sLeft, sMaxColor, sScan[16], sSharedBase;
 	const u32 tid = threadIdx.x;
 	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
 
 	for (u32 key = blockIdx.x; key < totalKeys; key += gridDim.x)
 	{
-		u32 first = taskStart[key], n = taskStart[key + 1] - first;
+		u32 first = taskStart[key * CL_SUBCOUNTERS], n = taskStart[(key + 1u) * CL_SUBCOUNTERS] - first;
 		ClTask* T = tasks + key;
 		if (!n) { if (tid == 0) { T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } continue; }
 		if (n > CL_TASK_MAX_MANIFOLDS) { if (tid == 0) { atomicOr(&counters[CTR_CL_STATUS], 2u); T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } continue; }
@@ -287,6 +308,12 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 		const u32 numShared = sNumShared, numBodies = sNumShared + sNumPrivate;
 		const bool tooMany = numBodies > CL_TASK_MAX_BODIES; // uniform
 		if (tooMany) { if (tid == 0) { atomicOr(&counters[CTR_CL_STATUS], 2u); T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } __syncthreads(); continue; }
+		// The task's shared bodies get a contiguous run of hand-over records (32 B each): its lanes publish them with coalesced stores, and
+		// whoever uses a body next finds the record through sharedSlot[phase][body].  (The placement of the run depends on the order the
+		// tasks get here; results do not.)
+		if (tid == 0) sSharedBase = atomicAdd(&counters[CTR_CL_SHARED], numShared);
+		__syncthreads();
+		const u32 sharedBase = sSharedBase;
 		for (u32 h = tid; h < CL_HASH_SIZE; h += CL_LANES)
 			if (hKey[h])
 			{
@@ -294,6 +321,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 				u32 l = (v & 0x80000000u) ? (v & 0x7FFFFFFFu) : numShared + v;
 				hVal[h] = l;
 				bodyList[(size_t)key * CL_BODY_STRIDE + l] = hKey[h] - 1u;
+				if (l < numShared) sharedSlot[(size_t)phase * (nb + 1u) + (hKey[h] - 1u)] = sharedBase + l;
 			}
 		for (u32 l = tid; l <= numBodies; l += CL_LANES) { mask[l] = 0ull; claim[l] = 0xFFFFFFFFu; }
 		__syncthreads();
@@ -313,6 +341,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			}
 			mAB[i] = loc[0] | (loc[1] << 16);
 			mKey[i] = 0xFFFFFFFFu;
+			mSlot[i] = (ids.w & 0x0FFFFFFFu) | (ids.z << 28);
 		}
 		__syncthreads();
 		// 3. colouring rounds
@@ -322,9 +351,8 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			for (u32 i = tid; i < n; i += CL_LANES)
 			{
 				if (mKey[i] != 0xFFFFFFFFu) continue;
-				uint4 idq = actIds[pre[first + i]];
-				u32 slot = idq.w;
-				u32 bid = clBid(slot, idq.z, round, i);
+				u32 sc = mSlot[i];
+				u32 bid = clBid(sc & 0x0FFFFFFFu, sc >> 28, round, i);
 				u32 ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16;
 				if (la != CL_LOCAL_STATIC) atomicMin(&claim[la], bid);
 				if (lb != CL_LOCAL_STATIC) atomicMin(&claim[lb], bid);
@@ -334,8 +362,8 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			for (u32 i = tid; i < n; i += CL_LANES)
 			{
 				if (mKey[i] != 0xFFFFFFFFu) continue;
-				uint4 ids = actIds[pre[first + i]];
-				u32 bid = clBid(ids.w, ids.z, round, i);
+				u32 sc = mSlot[i], cnt = sc >> 28;
+				u32 bid = clBid(sc & 0x0FFFFFFFu, cnt, round, i);
 				u32 ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16;
 				bool won = (la == CL_LOCAL_STATIC || claim[la] == bid) && (lb == CL_LOCAL_STATIC || claim[lb] == bid);
 				if (!won) { ++left; continue; }
@@ -347,7 +375,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 					if (lb != CL_LOCAL_STATIC) mask[lb] |= 1ull << c;
 					atomicMax(&sMaxColor, c + 1u);
 				}
-				mKey[i] = c * 4u + (4u - ids.z);
+				mKey[i] = c * 4u + (4u - cnt);
 			}
 			if (left) atomicAdd(&sLeft, left);
 			__syncthreads();
@@ -377,7 +405,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			T->first = first; T->count = n; T->numBodies = numBodies; T->numShared = numShared; T->numColors = numColors; T->serialStart = hist[CL_SERIAL_COLOR * 4u];
 			T->colorStart[CL_SERIAL_COLOR + 1u] = n;
 			atomicMax(&counters[CTR_NUM_COLORS], numColors + (hist[CL_SERIAL_COLOR * 4u] < n ? 1u : 0u));
-			atomicAdd(&counters[CTR_CL_SHARED], numShared);
+			T->sharedBase = sharedBase;
 			atomicAdd(&counters[CTR_CL_PHASE_COUNT + phase], n);
 		}
 		__syncthreads();
@@ -452,7 +480,7 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 struct ClLocal // a task of this workgroup, in LDS
 {
-	u32 first, count, numBodies, numShared, numColors, serialStart, phase, key;
+	u32 first, count, numBodies, numShared, numColors, serialStart, phase, key, sharedBase;
 	u32 bodyOff;   // float4 index of the task's bodies (2 float4 each)
 	u32 infoOff;   // u32 index (in float4 units * 4) of per-body {global id, turn info}
 	u32 metaOff;   // float4 index of the per-manifold meta (not for the register task): {la|lb<<16, key|extra<<10, -, -}, {n.xyz, friction}
@@ -480,7 +508,7 @@ MI_DEV float2 clLoadLambdaLds(const float4* lds, u32 rowOff, u32 rowCap, u32 row
 
 struct ClArgs
 {
-	u32* counters; const ClTask* tasks; const u32* bodyList; const u32* bodyUsers; const u32* phaseMask;
+	u32* counters; const ClTask* tasks; const u32* bodyList; const u32* bodyUsers; const u32* phaseMask; const u32* sharedSlot;
 	const u32* mKeySorted; const u32* mLocal; const u32* mExtra; const u32* mRank;
 	const float4* rowPlanes; const float4* rowShared; float2* rowLambda;
 	float4* vel; u64* flow; u64* trace; // trace: developer timeline (mi_debug_flow_trace), normally null
@@ -585,10 +613,10 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 			if (!T->count) continue;
 			ClLocal& L = sTask[nT];
 			L.first = T->first; L.count = T->count; L.numBodies = T->numBodies; L.numShared = T->numShared; L.numColors = T->numColors; L.serialStart = T->serialStart;
-			L.phase = p; L.key = key;
+			L.phase = p; L.key = key; L.sharedBase = T->sharedBase;
 			for (u32 c = 0; c <= CL_SERIAL_COLOR + 1u; ++c) L.colorStart[c] = T->colorStart[c];
 			L.bodyOff = used; used += 2u * L.numBodies;
-			L.infoOff = used * 4u; used += (2u * L.numBodies + 3u) / 4u;
+			L.infoOff = used * 4u; used += (3u * L.numBodies + 3u) / 4u;
 			L.inRegs = (nT == 0 && L.count <= CLS_LANES * CLS_R) ? 1u : 0u;
 			L.metaOff = used; if (!L.inRegs) used += 2u * L.count;
 			L.rowOff = 0; L.rowCap = 0;
@@ -625,7 +653,12 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 			u32 g = A.bodyList[(size_t)L.key * CL_BODY_STRIDE + l];
 			u32 pm = A.phaseMask[g];
 			u32 deg = __popc(pm), rank = __popc(pm & ((1u << L.phase) - 1u));
-			info[2 * l] = g; info[2 * l + 1] = deg | (rank << 8);
+			// where the body comes from: the record of the phase that used it last (the last phase of the previous iteration for this
+			// iteration's first user)
+			u32 below = pm & ((1u << L.phase) - 1u);
+			u32 prev = below ? 31u - (u32)__clz(below) : 31u - (u32)__clz(pm);
+			info[3 * l] = g; info[3 * l + 1] = deg | (rank << 8);
+			info[3 * l + 2] = (l < L.numShared) ? A.sharedSlot[(size_t)prev * (A.nb + 1u) + g] : 0u;
 			lds[L.bodyOff + 2 * l] = A.vel[2 * g]; lds[L.bodyOff + 2 * l + 1] = A.vel[2 * g + 1]; // shared ones too: .w = invMass stays, the rest is replaced at every acquire
 		}
 		if (L.inRegs)
@@ -691,39 +724,73 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 
 	// ---- iterations ----
 	bool aborted = false;
+	u64 lastPublish = 0; u32 lastWait = 0; // when this workgroup last handed its bodies on, and how long (10 ns ticks) the bodies of its first task then took to come back
 	for (u32 it = A.itBegin; it < A.itEnd && !aborted; ++it)
 	{
 		for (u32 k = 0; k < numTasks; ++k)
 		{
 			const ClLocal& L = sTask[k];
 			const u32* info = (const u32*)lds + L.infoOff;
-			// acquire the bodies other phases also touch
-			for (u32 l = tid; l < L.numShared; l += CLS_LANES)
+			// acquire the bodies other phases also touch.  The sweep is periodic: a task's bodies come back about one iteration
+			// period after they came back last time, so the workgroup sleeps through most of the previous wait before it polls (the
+			// polls are uncached loads through the fabric: 50k lanes polling all the time slow every hand-over down); then every lane
+			// polls the tagged first halves of up to four bodies per pass, all loads in flight together, and fetches the second half
+			// (stored before the first) once the tag has arrived.
 			{
-				u32 g = info[2 * l], ti = info[2 * l + 1];
-				u32 deg = ti & 0xFFu, rank = ti >> 8;
-				u32 want = A.epoch + (it - A.itBegin) * deg + rank;
-				if (it == A.itBegin && rank == 0u) continue; // first user of the launch: the prologue's copy of vel is current
-				u32 spins = 0;
-				for (;;)
+				if (k == 0 && lastWait > 64u && it > A.itBegin + 1u)
 				{
-					asm volatile("" ::: "memory");
-					u32x4 h0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64u, 0, 16);
-					u32x4 h1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, g * 64u + 16u, 0, 16);
-					if (h0.w == want && h1.w == want)
+					u64 until = lastPublish + (u64)(lastWait - lastWait / 4u);
+					while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
+				}
+				const u32 rel = it - A.itBegin;
+				for (u32 base = 0; base < L.numShared; base += 4u * CLS_LANES)
+				{
+					u32 gid[4], want[4]; bool pend[4]; bool any = false;
+#pragma unroll
+					for (u32 q = 0; q < 4; ++q)
 					{
-						float invMass = lds[L.bodyOff + 2 * l].w; // constant over the launch
-						lds[L.bodyOff + 2 * l] = make_float4(__uint_as_float(h0.x), __uint_as_float(h0.y), __uint_as_float(h0.z), invMass);
-						lds[L.bodyOff + 2 * l + 1] = make_float4(__uint_as_float(h1.x), __uint_as_float(h1.y), __uint_as_float(h1.z), 0.f);
-						break;
+						u32 l = base + q * CLS_LANES + tid;
+						pend[q] = false; gid[q] = 0; want[q] = 0;
+						if (l >= L.numShared) continue;
+						u32 ti = info[3 * l + 1], deg = ti & 0xFFu, rank = ti >> 8;
+						if (rel == 0u && rank == 0u) continue; // first user of the launch: the prologue's copy of vel is current
+						gid[q] = info[3 * l + 2]; want[q] = A.epoch + rel * deg + rank; pend[q] = true; any = true;
 					}
-					if (++spins > CL_SPIN_LIMIT) { atomicOr(status, 1u); sAbort = 1u; break; }
-					if ((spins & 63u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { sAbort = 1u; break; }
-					__builtin_amdgcn_s_sleep(1);
+					u32 spins = 0;
+					while (any)
+					{
+						u32x4 h0[4], h1[4];
+						asm volatile("" ::: "memory");
+#pragma unroll
+						for (u32 q = 0; q < 4; ++q)
+							if (pend[q]) { h0[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, gid[q] * 32u, 0, 16); h1[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, gid[q] * 32u + 16u, 0, 16); }
+						any = false;
+#pragma unroll
+						for (u32 q = 0; q < 4; ++q)
+						{
+							if (!pend[q]) continue;
+							if (h0[q].w == want[q] && h1[q].w == want[q]) // each half carries its own tag
+							{
+								u32 l = base + q * CLS_LANES + tid;
+								float invMass = lds[L.bodyOff + 2 * l].w; // constant over the launch
+								lds[L.bodyOff + 2 * l] = make_float4(__uint_as_float(h0[q].x), __uint_as_float(h0[q].y), __uint_as_float(h0[q].z), invMass);
+								lds[L.bodyOff + 2 * l + 1] = make_float4(__uint_as_float(h1[q].x), __uint_as_float(h1[q].y), __uint_as_float(h1[q].z), 0.f);
+								pend[q] = false;
+							}
+							any = any || pend[q];
+						}
+						if (any)
+						{
+							if (++spins > CL_SPIN_LIMIT) { atomicOr(status, 1u); sAbort = 1u; break; }
+							if ((spins & 63u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { sAbort = 1u; break; }
+							__builtin_amdgcn_s_sleep(1);
+						}
+					}
 				}
 			}
 			__syncthreads();
 			if (sAbort) { aborted = true; break; }
+			if (k == 0 && it > A.itBegin) lastWait = (u32)(wall_clock64() - lastPublish);
 			if (trace && tid == 0 && it - A.itBegin < 32u && k < 5u) trace[(3 * k) * 32 + (it - A.itBegin)] = wall_clock64();
 			// colours
 			if (L.inRegs)
@@ -739,7 +806,7 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 					__syncthreads();
 					if (stamp) { trace[5 * 32 + 1 + c] = clock64(); trace[7 * 32 + c] = L.colorStart[c + 1] - L.colorStart[c]; }
 				}
-				for (u32 sp = serialStart; sp < taskCount; ++sp)
+				for (u32 sp = serialStart; sp < taskCount; ++sp) // the serial tail (manifolds that found no colour below 64): one per step
 				{
 					if (tid == sp) clSolveReg(lds, A, rdA0, wrA0, rdB0, wrB0, regKE0, regSh0, regRow0, rowOff0, rowCap0, first0 + tid);
 					if (tid + CLS_LANES == sp) clSolveReg(lds, A, rdA1, wrA1, rdB1, wrB1, regKE1, regSh1, regRow1, rowOff0, rowCap0, first0 + tid + CLS_LANES);
@@ -771,19 +838,21 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 			// hand the shared bodies on
 			for (u32 l = tid; l < L.numShared; l += CLS_LANES)
 			{
-				u32 g = info[2 * l], ti = info[2 * l + 1];
+				u32 g = info[3 * l], ti = info[3 * l + 1];
 				u32 deg = ti & 0xFFu, rank = ti >> 8;
 				u32 want = A.epoch + (it - A.itBegin) * deg + rank;
+				u32 rec = (L.sharedBase + l) * 32u; // consecutive lanes, consecutive records: the write-through stores coalesce
 				float4 b0 = lds[L.bodyOff + 2 * l], b1 = lds[L.bodyOff + 2 * l + 1];
 				if (it + 1u == A.itEnd && rank + 1u == deg) { A.vel[2 * g] = b0; A.vel[2 * g + 1] = make_float4(b1.x, b1.y, b1.z, 0.f); } // last user of the launch
 				else
 				{
 					u32x4 h1 = { __float_as_uint(b1.x), __float_as_uint(b1.y), __float_as_uint(b1.z), want + 1u };
 					u32x4 h0 = { __float_as_uint(b0.x), __float_as_uint(b0.y), __float_as_uint(b0.z), want + 1u };
-					__builtin_amdgcn_raw_buffer_store_b128(h1, rsrc, g * 64u + 16u, 0, 16);
-					__builtin_amdgcn_raw_buffer_store_b128(h0, rsrc, g * 64u, 0, 16);
+					__builtin_amdgcn_raw_buffer_store_b128(h1, rsrc, rec + 16u, 0, 16);
+					__builtin_amdgcn_raw_buffer_store_b128(h0, rsrc, rec, 0, 16);
 				}
 			}
+			if (k + 1u == numTasks) lastPublish = wall_clock64();
 		}
 	}
 	if (aborted) return; // the host redoes the step (World::recoverSolve)
@@ -795,7 +864,7 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 		const u32* info = (const u32*)lds + L.infoOff;
 		for (u32 l = L.numShared + tid; l < L.numBodies; l += CLS_LANES)
 		{
-			u32 g = info[2 * l];
+			u32 g = info[3 * l];
 			float4 b1 = lds[L.bodyOff + 2 * l + 1];
 			A.vel[2 * g] = lds[L.bodyOff + 2 * l]; A.vel[2 * g + 1] = make_float4(b1.x, b1.y, b1.z, 0.f);
 		}
@@ -838,7 +907,7 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 // ---------------------------------------------------------------------------------------------------------------
 static size_t clColorLdsBytes()
 {
-	return sizeof(u32) * (2 * CL_HASH_SIZE + (CL_TASK_MAX_BODIES + 1) + 4 * CL_TASK_MAX_MANIFOLDS + 264) + sizeof(u64) * (CL_TASK_MAX_BODIES + 1);
+	return sizeof(u32) * (2 * CL_HASH_SIZE + (CL_TASK_MAX_BODIES + 1) + 5 * CL_TASK_MAX_MANIFOLDS + 264) + sizeof(u64) * (CL_TASK_MAX_BODIES + 1);
 }
 
 bool cluster_available(World& w)
@@ -866,53 +935,59 @@ bool cluster_available(World& w)
 void launch_cluster_build(World& w, u32 numPairs)
 {
 	if (!numPairs) return;
-	u32 nb = w.nb, P = w.clusterParts;
+	u32 nb = w.nb;
 	size_t nb1 = (size_t)nb + 1;
+	{ const u32 P = CL_MAX_PARTS;
 	w.clKeys.ensure((size_t)P * nb, w.stream); w.clKeysSorted.ensure((size_t)P * nb, w.stream); w.clVals.ensure((size_t)P * nb, w.stream); w.clSorted.ensure((size_t)P * nb, w.stream);
-	w.clRank.ensure((size_t)P * nb1, w.stream); w.clWsum.ensure(2 * nb1, w.stream); w.clCum.ensure(nb1, w.stream); w.clPhaseMask.ensure(nb1, w.stream);
+	w.clRank.ensure((size_t)P * nb1, w.stream); w.clSharedSlot.ensure((size_t)CL_MAX_PHASES * nb1, w.stream); w.clWsum.ensure(P * nb1, w.stream); w.clCum.ensure(nb1, w.stream); w.clPhaseMask.ensure(nb1, w.stream); }
 	w.clTaskKey.ensure(w.pairCap, w.stream); w.clTaskPos.ensure(w.pairCap, w.stream); w.clPre.ensure(w.pairCap, w.stream); w.clLocal.ensure(w.pairCap, w.stream); w.clExtra.ensure(w.pairCap, w.stream); w.clRankInfo.ensure(w.pairCap, w.stream);
 	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
-	w.clTaskCount.ensure(totalKeys, w.stream); w.clTaskStart.ensure(totalKeys + 1, w.stream);
+	w.clTaskCount.ensure(totalKeys * CL_SUBCOUNTERS, w.stream); w.clTaskStart.ensure(totalKeys * CL_SUBCOUNTERS + 1, w.stream);
 	w.clTasks.ensure((size_t)totalKeys * sizeof(ClTask), w.stream); w.clBodyList.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream); w.clBodyUsers.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream);
 	if (w.lastError) return;
 
 	dim3 bgrid((nb + 255) / 256), block(256), mgrid((numPairs + 255) / 256);
 	// active manifolds (k_active_list of the colouring: also counts contacts); no warm colours, no global colour masks
 	launch_active_list(w, numPairs);
-	// body order (any order is correct; this one makes the clusters compact)
-	ClShifts sh; u32 maxShift = 0;
-	for (u32 p = 0; p < CL_MAX_PARTS; ++p) for (u32 k = 0; k < 3; ++k) { sh.s[p][k] = w.clusterShift[p][k]; maxShift = std::max(maxShift, sh.s[p][k]); }
-	hipLaunchKernelGGL(k_cl_bbox, dim3(std::min<u32>(bgrid.x, 64u)), block, 0, w.stream, nb, w.cog.p, w.simMask.p, w.dCounters.p);
-	hipLaunchKernelGGL(k_cl_keys, bgrid, block, 0, w.stream, nb, P, sh, maxShift, w.cog.p, w.simMask.p, w.dCounters.p, w.clKeys.p, w.clVals.p);
-	for (u32 p = 0; p < P; ++p)
-		prim_sort_pairs_u32(w, w.clKeys.p + (size_t)p * nb, w.clKeysSorted.p + (size_t)p * nb, w.clVals.p + (size_t)p * nb, w.clSorted.p + (size_t)p * nb, nb, 30);
-	hipLaunchKernelGGL(k_cl_ranks, bgrid, block, 0, w.stream, nb, P, w.clSorted.p, w.clRank.p);
-	// tasks
-	MI_CHECK(hipMemsetAsync(w.clWsum.p, 0, sizeof(u32) * 2 * nb1, w.stream));
-	MI_CHECK(hipMemsetAsync(w.clPhaseMask.p, 0, sizeof(u32) * nb1, w.stream));
-	MI_CHECK(hipMemsetAsync(w.clTaskCount.p, 0, sizeof(u32) * totalKeys, w.stream));
-	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CL_STATUS, 0, sizeof(u32) * 7, w.stream)); // status, shared bodies, manifolds per phase
-	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CL_REMAIN, 0, sizeof(u32) * 6, w.stream));
-	hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, w.clWsum.p, w.clTaskKey.p);
-	for (u32 p = 0; p < P; ++p)
+	// Body order along the phases' curves.  Any order is correct, this one makes the clusters compact; bodies move a fraction of
+	// their size per step, so the order is refreshed every few steps only (four radix sorts of all bodies), at once when bodies were
+	// added and after a snapshot was taken or restored (so that a restored world and its original keep making the same choices).
+	const u32 P = CL_MAX_PARTS; // all curves, whatever the number of partition phases in use: that number adapts from step to step
+	if (w.clusterSortDue || w.clusterSortAge >= w.clusterSortInterval || w.clusterSortBodies != nb)
 	{
-		u32* wsum = w.clWsum.p + (size_t)(p & 1u) * nb1; u32* wsumNext = w.clWsum.p + (size_t)((p + 1u) & 1u) * nb1;
-		prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
-		if (p + 1 < P) MI_CHECK(hipMemsetAsync(wsumNext, 0, sizeof(u32) * nb1, w.stream));
-		hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, P, w.clusterTaskWeight, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
-			w.clRank.p + (size_t)std::min(p + 1, P - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
+		ClShifts sh; u32 maxShift = 0;
+		for (u32 p = 0; p < CL_MAX_PARTS; ++p) for (u32 k = 0; k < 3; ++k) { sh.s[p][k] = w.clusterShift[p][k]; maxShift = std::max(maxShift, sh.s[p][k]); }
+		hipLaunchKernelGGL(k_cl_bbox, dim3(std::min<u32>(bgrid.x, 64u)), block, 0, w.stream, nb, w.cog.p, w.simMask.p, w.dCounters.p);
+		hipLaunchKernelGGL(k_cl_keys, bgrid, block, 0, w.stream, nb, P, sh, maxShift, w.cog.p, w.simMask.p, w.dCounters.p, w.clKeys.p, w.clVals.p);
+		for (u32 p = 0; p < P; ++p)
+			prim_sort_pairs_u32(w, w.clKeys.p + (size_t)p * nb, w.clKeysSorted.p + (size_t)p * nb, w.clVals.p + (size_t)p * nb, w.clSorted.p + (size_t)p * nb, nb, 30);
+		hipLaunchKernelGGL(k_cl_ranks, bgrid, block, 0, w.stream, nb, P, w.clSorted.p, w.clRank.p);
+		w.clusterSortDue = false; w.clusterSortAge = 0; w.clusterSortBodies = nb;
 	}
-	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, P, w.clTaskCount.p, w.clTaskStart.p);
+	w.clusterSortAge++;
+	// tasks
+	const u32 parts = w.clusterParts;
+	u32 clearItems = std::max<u32>((u32)(CL_MAX_PARTS * nb1), totalKeys * CL_SUBCOUNTERS);
+	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.dCounters.p);
+	hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, w.clWsum.p, w.clTaskKey.p);
+	for (u32 p = 0; p < parts; ++p)
+	{
+		u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
+		prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
+		hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, w.clusterTaskWeight, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
+			w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
+	}
+	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, parts, w.clTaskCount.p, w.clTaskStart.p);
 	hipLaunchKernelGGL(k_cl_scatter, mgrid, block, 0, w.stream, w.dCounters.p, w.clTaskKey.p, w.clTaskPos.p, w.clTaskStart.p, w.clPre.p);
 	hipLaunchKernelGGL(k_cl_color, dim3(w.clusterBlocks), dim3(CL_LANES), clColorLdsBytes(), w.stream, w.dCounters.p, nb, w.clTaskStart.p, w.clPre.p, w.actIds.p,
-		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.clBodyUsers.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clExtra.p, w.clRankInfo.p);
+		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.clBodyUsers.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clExtra.p, w.clRankInfo.p, w.clSharedSlot.p);
 }
 
 // Iterations [itBegin, itEnd) of the contact sweep in one launch.
 void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd)
 {
 	if (itBegin >= itEnd) return;
-	size_t words = (size_t)(w.nb + 1) * 8;
+	size_t words = (size_t)(w.nb + 1) * CL_MAX_PHASES * 4; // one 32-byte hand-over record per (phase, body) at most
 	if (w.flow.cap < words) { w.flow.ensure(words, w.stream); w.flowEpoch = 0; }
 	if (w.flowEpoch == 0 || w.flowEpoch >= 0xFFFEu) // first use or the turn counter about to wrap: no stale record may ever match
 	{
@@ -927,7 +1002,7 @@ void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd)
 		MI_CHECK(hipStreamSynchronize(w.stream));
 	}
 	ClArgs A;
-	A.counters = w.dCounters.p; A.tasks = (const ClTask*)w.clTasks.p; A.bodyList = w.clBodyList.p; A.bodyUsers = w.clBodyUsers.p; A.phaseMask = w.clPhaseMask.p;
+	A.counters = w.dCounters.p; A.tasks = (const ClTask*)w.clTasks.p; A.bodyList = w.clBodyList.p; A.bodyUsers = w.clBodyUsers.p; A.phaseMask = w.clPhaseMask.p; A.sharedSlot = w.clSharedSlot.p;
 	A.mKeySorted = w.mKeySorted.p; A.mLocal = w.clLocal.p; A.mExtra = w.clExtra.p; A.mRank = w.clRankInfo.p;
 	A.rowPlanes = w.rowPlanes.p; A.rowShared = w.rowShared.p; A.rowLambda = w.rowLambda.p; A.vel = w.vel.p; A.flow = w.flow.p; A.trace = w.flowTrace.p;
 	A.rowCap = w.rowCap; A.nb = w.nb; A.flowBytes = (u32)(words * sizeof(u64)); A.epoch = w.flowEpoch << 16; A.itBegin = itBegin; A.itEnd = itEnd;

@@ -177,8 +177,9 @@ struct World
 	bool lastStepCluster = false, backupVelocities = false;
 	u32 clusterParts = 3, clusterTaskWeight = 64u * 960u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
 	bool clusterPartsFixed = false;       // MI_CLUSTER_PARTS given: no adaptation
+	bool clusterSortDue = true; u32 clusterSortAge = 0, clusterSortInterval = 8, clusterSortBodies = 0; // body order along the curves: refreshed every few steps (MI_CLUSTER_SORT_INTERVAL)
 	u32 clusterLdsBytes = 0, clusterBlocks = 0, clusterCooldown = 0;
-	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clExtra, clTaskCount, clTaskStart, clBodyList, clBodyUsers, clRankInfo;
+	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clExtra, clTaskCount, clTaskStart, clBodyList, clBodyUsers, clRankInfo, clSharedSlot;
 	DevBuf<uint8_t> clTasks;
 	DevBuf<u64> flowTrace;                // developer timeline (mi_debug_flow_trace): 32 x u64 per slot, allocated on request only
 	u32 flowEpoch = 0, flowMaxBlocks[2] = { 0, 0 };

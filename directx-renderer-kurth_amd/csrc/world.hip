@@ -54,6 +54,7 @@ World::World(int dev) : device(dev)
 	if (const char* e = getenv("MI_COLOR_FULL_INTERVAL")) fullColoringInterval = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_TEST_ABORT")) flowTestAbortStep = (u32)atoi(e); // tests: make the cluster sweep of that internal step give up
 	if (const char* e = getenv("MI_CLUSTER_PARTS")) { clusterParts = std::min<u32>(CL_MAX_PARTS, std::max(1, atoi(e))); clusterPartsFixed = true; }
+	if (const char* e = getenv("MI_CLUSTER_SORT_INTERVAL")) clusterSortInterval = (u32)std::max(1, atoi(e));
 	if (const char* e = getenv("MI_CLUSTER_TASK")) clusterTaskWeight = 64u * (u32)std::max(16, atoi(e));   // manifolds per task
 	if (const char* e = getenv("MI_CLUSTER_SHIFT")) { int a = 0, b = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) for (u32 p = 1; p < CL_MAX_PARTS; ++p) { clusterShift[p][0] = (u32)a * p; clusterShift[p][1] = (u32)b * p; clusterShift[p][2] = (u32)c * p; } }
 	if (dCounters.p)
@@ -1032,6 +1033,7 @@ int mi_snapshot_save(mi_world* world, void* buffer, uint64_t capacity)
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	BlobWriter out; serialize(*W, out);
 	if (W->lastError) return W->lastError;
+	W->clusterSortDue = true; // the restored world orders its bodies at its first step: so does this one at its next
 	if (!buffer || capacity < out.bytes.size()) { W->fail(MI_ERR_CAPACITY, "mi_snapshot_save: buffer too small (ask mi_snapshot_size)"); return MI_ERR_CAPACITY; }
 	memcpy(buffer, out.bytes.data(), out.bytes.size());
 	return MI_OK;

@@ -42,3 +42,9 @@ for wg in np.argsort(-(raw[:, 15, 3] * ((raw[:, 15, 5] & 0xFF) == 0)))[:2]:
     nc = int(raw[wg, 15, 3])
     cyc = raw[wg, 5:7].reshape(-1)[:nc + 1]; sizes = raw[wg, 7:9].reshape(-1)[:nc]
     print("workgroup %d: %d manifolds, %d colours; cycles per colour %s; manifolds per colour %s" % (wg, raw[wg, 15, 2], nc, np.diff(cyc).tolist(), sizes.tolist()))
+# hop latencies in iteration 10: when each phase's tasks finished their colours / had acquired their bodies
+ph_all = raw[:, 15, 5] & 0xFF
+for p in np.unique(ph_all[has]):
+    q = has & (ph_all == p)
+    a = us(raw[q, 0, 10]); c = us(raw[q, 1, 10]); a11 = us(raw[q, 0, 11])
+    print("phase %d it10: acquired min %.2f med %.2f max %.2f | colours done min %.2f med %.2f max %.2f | it11 acquired min %.2f max %.2f" % (p, a.min(), np.median(a), a.max(), c.min(), np.median(c), c.max(), a11.min(), a11.max()))
