@@ -104,7 +104,10 @@ class Scene:
                 world.add_collider(body, ctype, shape, mat)
         for j in self.joints:
             kind, a, b, args = j[0], j[1], j[2], j[3:]
-            getattr(world, "add_%s_constraint_global" % kind)(a, b, *args)
+            if kind.endswith("_local"):   # add*ConstraintFromLocalPoints (physics.h:209-235)
+                getattr(world, "add_%s_constraint_local" % kind[:-6])(a, b, *args)
+            else:
+                getattr(world, "add_%s_constraint_global" % kind)(a, b, *args)
         kinds = {"distance": (0, 28), "ball": (1, 24), "fixed": (2, 40), "hinge": (3, 104), "cone_twist": (4, 120), "slider": (5, 72)}
         for kind, index, edits in self.joint_edits:
             ctype, nbytes = kinds[kind]
@@ -692,7 +695,66 @@ def c4_ragdolls(n=256, pitch=3.0, hip_y=1.25):
     return s
 
 
+def joints_mix():
+    """Every joint kind the BASELINE configs leave out, on the ground so that contacts and joints meet in one solve: two hanging
+    chains held by DISTANCE joints (one added from global points, one from local points, each from a kinematic anchor), a chain of
+    BALL joints added from local points, and a three-link CONE-TWIST chain whose swing and twist motors run (velocity motor on one
+    joint, angle motor on the other: constraints.cpp:1880-1960), all above a pile of loose bodies they fall into."""
+    s = Scene("joints_mix", dt=1.0 / 120.0)
+    _ground(s, 30.0)
+    mat = (0.1, 0.6, 2.0)
+
+    def link(pos, kinematic=False, radius=0.25):
+        b = s.add_body(pos, kinematic=kinematic)
+        s.add_collider(b, SPHERE, (0.0, 0.0, 0.0, radius), mat)
+        return b
+
+    # distance chain from global points
+    prev = link((-3.0, 6.0, 0.0), kinematic=True)
+    for i in range(6):
+        cur = link((-3.0 + 0.7 * (i + 1), 6.0, 0.0))
+        s.add_joint("distance", prev, cur, (-3.0 + 0.7 * i, 6.0, 0.0), (-3.0 + 0.7 * (i + 1), 6.0, 0.0))
+        prev = cur
+    # distance chain from local points (anchors 0.1 off the centres, rest length given)
+    prev = link((3.0, 6.0, 1.0), kinematic=True)
+    for i in range(6):
+        cur = link((3.0, 6.0, 1.0 + 0.8 * (i + 1)))
+        s.add_joint("distance_local", prev, cur, (0.0, 0.0, 0.1), (0.0, 0.0, -0.1), 0.6)
+        prev = cur
+    # ball chain from local points
+    prev = link((0.0, 7.0, -3.0), kinematic=True)
+    for i in range(5):
+        cur = link((0.0, 7.0 - 0.6 * (i + 1), -3.0))
+        s.add_joint("ball_local", prev, cur, (0.0, -0.3, 0.0), (0.0, 0.3, 0.0))
+        prev = cur
+    # cone-twist chain with motors
+    base = s.add_body((0.0, 3.0, 3.0), kinematic=True)
+    s.add_collider(base, OBB, (0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.3, 0.3, 0.3), mat)
+    prev = base
+    for i in range(3):
+        cur = s.add_body((0.9 * (i + 1), 3.0, 3.0))
+        s.add_collider(cur, CAPSULE, (-0.25, 0.0, 0.0, 0.25, 0.0, 0.0, 0.15), mat)
+        s.add_joint("cone_twist", prev, cur, (0.9 * i + 0.45, 3.0, 3.0), (1.0, 0.0, 0.0), 0.9, 0.7)
+        prev = cur
+    # joint 0: swing velocity motor about the tangent axis; joint 1: twist angle motor; joint 2: both (mi_cone_twist_constraint byte offsets)
+    s.joint_edits.append(("cone_twist", 0, [(92, "u4", 0), (96, "f4", 1.5), (100, "f4", 40.0), (104, "f4", 0.3)]))
+    s.joint_edits.append(("cone_twist", 1, [(108, "u4", 1), (112, "f4", 0.5), (116, "f4", 30.0)]))
+    s.joint_edits.append(("cone_twist", 2, [(92, "u4", 1), (96, "f4", 0.4), (100, "f4", 25.0), (104, "f4", 1.2), (108, "u4", 0), (112, "f4", -1.0), (116, "f4", 20.0)]))
+    # loose bodies underneath
+    rng = XorShift64(77120451)
+    for i in range(60):
+        pos = (rng.between(-4.0, 4.0), rng.between(0.4, 2.5), rng.between(-4.0, 4.0))
+        b = s.add_body(pos, rng.unit_quat())
+        if i % 2:
+            s.add_collider(b, OBB, (0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, rng.between(0.2, 0.4), rng.between(0.2, 0.4), rng.between(0.2, 0.4)), mat)
+        else:
+            s.add_collider(b, SPHERE, (0.0, 0.0, 0.0, rng.between(0.2, 0.4)), mat)
+    return s
+
+
 def by_name(name):
+    if name == "joints_mix":
+        return joints_mix()
     if name == "c1":
         return c1_boxes()
     if name == "c2":

@@ -286,6 +286,12 @@ class OracleWorld:
         """Custom-order contact solves in the device's row form (default) or with the reference formula."""
         self.lib.orc_set_row_form(self.w, int(on))
 
+    def stage_seconds(self, reset=True):
+        """Cumulative wall time per stage since the last reset: colliders + broadphase, narrowphase, forces + constraint setup, solve, integration."""
+        out = np.zeros(5, np.float64)
+        self.lib.orc_stage_seconds(self.w, _p(out), int(reset))
+        return out
+
     def clear_follow(self):
         self.lib.orc_clear_follow(self.w)
 

@@ -10,6 +10,7 @@
 #include "ocloth.h"
 #include "oheightmap.h"
 #include <vector>
+#include <chrono>
 #include <cstdio>
 #include <map>
 
@@ -112,6 +113,7 @@ struct world
 
 	// Optional external GS order for contacts: a permutation (or subset order) of contact indices.
 	std::vector<u32> customOrder;
+	double stageSeconds[5] = { 0, 0, 0, 0, 0 }; // cumulative wall time per stage (colliders + broadphase, narrowphase, forces + constraint setup, solve, velocity integration): cpu_baseline's breakdown
 	bool rowForm = true; // custom-order solves use the device's row form (solveCollisionConstraintRowForm); false = the reference formula
 	// "Follow" mode for whole-step parity with a device run: the narrowphase consumes an externally ordered candidate-pair list
 	// (slots) instead of prune/classify/bucket, contacts are solved manifold by manifold in `slotOrder`, joints in `jointOrder[t]`.
@@ -786,8 +788,11 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 	if (numRigidBodies == 0) { return; }
 	u32 dummyRigidBodyIndex = numRigidBodies;
 
+	auto stageClock = std::chrono::steady_clock::now();
+	auto stageEnd = [&](int stage) { auto now = std::chrono::steady_clock::now(); w.stageSeconds[stage] += std::chrono::duration<double>(now - stageClock).count(); stageClock = now; };
 	getWorldSpaceColliders(w);
 	broadphase(w);
+	stageEnd(0);
 	hullGeometryTable() = &w.hullGeometries;
 	if (w.usePairOverride) { narrowphaseOverride(w); }
 	else
@@ -796,6 +801,7 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 		if (w.hasTerrain) { heightmapCollision(w); }                               // :1236-1249
 	}
 
+	stageEnd(1);
 	vec3 globalForce;
 	bool anyGlobalForce = globalForceField(w, globalForce);                        // :1253 (a world without global fields skips the += 0 of :1273)
 	if (!w.forceFields.empty() || !w.triggers.empty() || !w.prevFrameTriggerOverlaps.empty()) { handleNonCollisionInteractions(w); } // :1255
@@ -866,6 +872,7 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 		for (u32 i = 0; i < numContacts; ++i) initializeCollisionConstraint(w.contactConstraints[i], rbs, w.contacts[i], w.contactBodyPairs[i], dt);
 	}
 
+	stageEnd(2);
 	for (u32 it = 0; it < iterations; ++it) // solveOneIteration (constraints.cpp:3748-3772)
 	{
 		for (u32 i : dO) solveDistanceConstraint(dU[i], rbs);
@@ -886,7 +893,9 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 		}
 	}
 
+	stageEnd(3);
 	for (u32 i = 0; i < numRigidBodies; ++i) { integrateVelocity(w.bodies[i], w.rbGlobal[i], w.bodies[i].transform1, dt); }
+	stageEnd(4);
 
 	for (cloth& c : w.cloths) // physics.cpp:1354-1358
 	{
@@ -1443,6 +1452,7 @@ int orc_step(world* w, float* timer, const physics_settings* settings, u32 mode,
 int orc_step_internal(world* w, u32 iterations, u32 mode, float dt) { physicsStepInternal(*w, iterations, mode, dt); return 0; }
 void orc_set_custom_order(world* w, const u32* order, u32 n) { w->customOrder.assign(order, order + n); }
 void orc_set_row_form(world* w, int on) { w->rowForm = on != 0; }
+void orc_stage_seconds(world* w, double* out5, int reset) { for (int i = 0; i < 5; ++i) { out5[i] = w->stageSeconds[i]; if (reset) w->stageSeconds[i] = 0; } }
 // Follow mode (see struct world): ordered candidate pairs + manifold execution order; n = 0 switches it off.
 void orc_set_follow(world* w, const u32* pairs2, u32 numPairs, const u32* slotOrder, u32 numOrder)
 {

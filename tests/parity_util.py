@@ -20,7 +20,34 @@ def quat_dist(a, b):
     return np.minimum(d1, d2)
 
 
-def follow_step(gpu, orc_world, scene_dt, iterations=30, joint_counts=None, resync=False):
+def own_narrowphase_check(orc_world, o_pairs, slots, g_counts, tie_pairs=None):
+    """The oracle's OWN prune + narrowphase on its OWN broadphase pairs (collision_narrow.cpp:2358-2379, restated here on the oracle's
+    world-space colliders) against what the device kept: the SET of colliding collider pairs and the contact total must agree.  In
+    follow mode the oracle evaluates the device's post-classify pair list, so a pair the device pruned by mistake would be invisible
+    there; here it shows up as a missing colliding pair.  tie_pairs: the endpoint-tie pairs the reference's sweep drops and the device
+    reports (accepted by follow_step); they are added to the oracle's list so that both sides test the same candidates."""
+    from oracle import oracle as orc
+    RIGID, STATIC = 0, 1  # physics_object_type (oracle/oshapes.h:198-201)
+    cols, _ = orc_world.world_colliders()
+    p = np.asarray(o_pairs, np.int64).reshape(-1, 2)
+    if tie_pairs is not None and len(tie_pairs):
+        t = np.asarray(tie_pairs, np.uint64)
+        p = np.concatenate([p, np.stack([(t & np.uint64(0xFFFFFFFF)).astype(np.int64), (t >> np.uint64(32)).astype(np.int64)], axis=1)])
+    ta, tb = cols["objectType"][p[:, 0]], cols["objectType"][p[:, 1]]
+    ia, ib = cols["objectIndex"][p[:, 0]], cols["objectIndex"][p[:, 1]]
+    keep = ((ta == RIGID) | (tb == RIGID)) & ~((ta == RIGID) & (tb == RIGID) & (ia == ib))       # :2358-2369
+    keep &= ((ta == RIGID) & (tb == RIGID)) | (ta == STATIC) | (tb == STATIC)                      # collisions only (:2378-2379)
+    p = p[keep]
+    swap = cols["type"][p[:, 0]] > cols["type"][p[:, 1]]                                          # typeA <= typeB (:2374)
+    p[swap] = p[swap][:, ::-1]
+    orc_world.use_hull_geometries()
+    _, counts = orc.narrowphase_ordered(cols, p.astype(np.uint32))
+    own = pair_set(p[counts > 0]); dev = pair_set(np.asarray(slots)[np.asarray(g_counts) > 0])
+    return {"own_colliding_equal": bool(np.array_equal(own, dev)), "own_missing_on_device": int(len(np.setdiff1d(own, dev))),
+            "own_extra_on_device": int(len(np.setdiff1d(dev, own))), "own_contacts": int(counts.sum()), "device_contacts": int(np.asarray(g_counts).sum())}
+
+
+def follow_step(gpu, orc_world, scene_dt, iterations=30, joint_counts=None, resync=False, own_narrowphase=False):
     """Step both worlds once; returns a dict of comparison metrics.  `orc_world.solver` must be SOLVER_CUSTOM.
     resync=True copies the oracle's state into the device world after the comparison, so every step starts from identical
     inputs (used where libm-vs-device trigonometry makes free-running trajectories drift chaotically: joints)."""
@@ -39,6 +66,7 @@ def follow_step(gpu, orc_world, scene_dt, iterations=30, joint_counts=None, resy
     gs, os_ = pair_set(g_pairs), pair_set(o_pairs)
     pairs_ok = np.array_equal(gs, os_)
     num_ties = 0
+    tie_pairs = None
     if not pairs_ok:
         # The reference's sort-and-sweep drops a pair whose endpoints TIE on the sorting axis depending on the previous frame's
         # endpoint order (stable insertion sort with '>', collision_broad.cpp:387-398) although aabbVsAABB is inclusive
@@ -50,6 +78,7 @@ def follow_step(gpu, orc_world, scene_dt, iterations=30, joint_counts=None, resy
         tie = (aabbs[i, 3 + axis] == aabbs[j, axis]) | (aabbs[j, 3 + axis] == aabbs[i, axis])
         pairs_ok = len(missing) == 0 and bool(tie.all())
         num_ties = int(len(extra))
+        tie_pairs = extra if pairs_ok else None
     out = {
         "pairs_equal": pairs_ok, "num_tie_pairs": num_ties,
         "num_pairs": len(g_pairs), "num_slots": len(slots), "num_manifolds": int((g_counts > 0).sum()),
@@ -65,6 +94,8 @@ def follow_step(gpu, orc_world, scene_dt, iterations=30, joint_counts=None, resy
         out["contact_normal_err"] = float(np.abs(gc["normal"] - oc["normal"]).max()) if len(oc) else 0.0
         out["contact_fr_equal"] = bool(np.array_equal(gc["friction_restitution"], oc["friction_restitution"])) if len(oc) else True
         out["num_contacts"] = int(len(oc))
+    if own_narrowphase:
+        out.update(own_narrowphase_check(orc_world, o_pairs, slots, g_counts, tie_pairs))
     gt, ot = gpu.transforms(1), orc_world.transforms(1)
     gv, ov = gpu.velocities(), orc_world.velocities()
     out["pos_err"] = float(np.abs(gt[:, :3] - ot[:, :3]).max())
