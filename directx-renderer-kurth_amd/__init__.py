@@ -67,14 +67,14 @@ TRIGGER_ENTER, TRIGGER_LEAVE, COLLISION_BEGIN, COLLISION_END = range(4)
 EXPORTED_SYMBOLS = [
     "mi_world_create", "mi_world_destroy", "mi_last_error", "mi_snapshot_size", "mi_snapshot_save", "mi_world_restore", "mi_add_body", "mi_add_hull_geometry", "mi_add_collider", "mi_add_static_collider",
     "mi_add_distance_constraint_local", "mi_add_distance_constraint_global", "mi_add_ball_constraint_local", "mi_add_ball_constraint_global",
-    "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global",
+    "mi_add_fixed_constraint_global", "mi_add_hinge_constraint_global", "mi_add_cone_twist_constraint_global", "mi_add_slider_constraint_global", "mi_add_constraint",
     "mi_constraint_get", "mi_constraint_set", "mi_delete_constraint", "mi_delete_all_constraints", "mi_delete_all_constraints_from_body", "mi_delete_body",
     "mi_add_force_field", "mi_set_force_field", "mi_add_trigger", "mi_add_force_field_collider", "mi_add_trigger_collider", "mi_set_force_field_transform", "mi_set_trigger_transform", "mi_enable_collision_events", "mi_drain_events",
     "mi_set_heightmap", "mi_heightmap_set_chunk", "mi_heightmap_update", "mi_heightmap_height_at",
     "mi_add_cloth", "mi_cloth_set_fixed_vertices", "mi_cloth_set_properties", "mi_set_cloth_iterations", "mi_num_cloths", "mi_cloth_num_particles", "mi_cloth_read",
     "mi_test_physics_interaction", "mi_apply_force_torque", "mi_set_velocity",
     "mi_set_transform", "mi_write_transforms", "mi_write_velocities", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
-    "mi_get_stats", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_debug_num_pairs", "mi_debug_read_pairs",
+    "mi_get_stats", "mi_enable_validation", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_debug_num_pairs", "mi_debug_read_pairs",
     "mi_debug_read_world_colliders", "mi_debug_num_manifold_slots", "mi_debug_read_manifolds", "mi_debug_num_colors", "mi_debug_read_schedule",
     "mi_debug_read_joint_order", "mi_debug_read_body_state", "mi_debug_flow_trace",
 ]
@@ -285,6 +285,15 @@ class World:
         self._check(self.lib.mi_cloth_read(self.w, C.c_uint32(cloth), _p(p), _p(v)))
         return p, v
 
+    def add_constraint(self, ctype, a, b, pod):
+        """addConstraint(a, b, const T&) (reference physics.h:239-244): the constraint as its POD bytes (layout of constraint_get)."""
+        buf = np.ascontiguousarray(np.frombuffer(bytes(pod), np.uint8))
+        assert len(buf) == (28, 24, 40, 104, 120, 72)[ctype]
+        cid = self.lib.mi_add_constraint(self.w, C.c_uint32(ctype), C.c_uint32(a), C.c_uint32(b), _p(buf))
+        if cid == 0xFFFFFFFF:
+            self._check(1)
+        return cid
+
     def add_distance_constraint_local(self, a, b, la, lb, distance):
         return self._id(self.lib.mi_add_distance_constraint_local(self.w, a, b, _f(la), _f(lb), C.c_float(distance)))
 
@@ -383,6 +392,11 @@ class World:
         out = np.zeros((self.num_bodies, 13), np.float32)
         self._check(self.lib.mi_read_mass_properties(self.w, _p(out), C.c_uint32(len(out))))
         return out
+
+    def enable_validation(self, on=True):
+        """Debug guard: NaN / Inf scan after every stage (the reference's VALIDATE macros, physics.cpp:807-926); a step after one that
+        produced a non-finite value fails."""
+        self._check(self.lib.mi_enable_validation(self.w, int(on)))
 
     def stats(self):
         s = Stats()

@@ -276,3 +276,36 @@ void launch_and_mask(World& w)
 {
 	if (w.nb) hipLaunchKernelGGL(k_and_mask, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, w.simMask.p, w.aliveMask.p);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Debug guard (MI_PHYSICS_VALIDATE=1): the reference's VALIDATE macros (physics.cpp:807-926, compiled out there with #if 0) print
+// every NaN / Inf in the world-space colliders and boxes, the contacts, the body update records; here a kernel per stage counts
+// them and remembers the first offender, and the step fails with MI_ERR_INVALID_STATE at its next synchronisation.
+// ---------------------------------------------------------------------------------------------------------------
+MI_DEV bool finite4(float4 v, bool w) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && (!w || isfinite(v.w)); }
+// One element = `stride` float4 at a[i * stride]; the first `check` of them are tested, .w included for the first `checkW`.
+__global__ void __launch_bounds__(256) k_validate(u32 stage, u32 n, const float4* __restrict__ a, u32 stride, u32 check, u32 checkW, const u32* __restrict__ countSrc, u32* __restrict__ counters)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (countSrc) n = min(n, *countSrc);
+	if (i >= n) return;
+	bool ok = true;
+	for (u32 k = 0; k < check; ++k) ok = ok && finite4(a[(size_t)i * stride + k], k < checkW);
+	if (!ok && atomicAdd(&counters[CTR_VALIDATE], 1u) == 0u) counters[CTR_VALIDATE + 1] = (stage << 28) | (i & 0x0FFFFFFFu);
+}
+void launch_validate(World& w, u32 stage, u32 numPairs)
+{
+	if (!w.validate) return;
+	dim3 block(256);
+	auto run = [&](u32 n, const void* p, u32 stride, u32 check, u32 checkW, const u32* countSrc) { if (n) hipLaunchKernelGGL(k_validate, dim3((n + 255) / 256), block, 0, w.stream, stage, n, (const float4*)p, stride, check, checkW, countSrc, w.dCounters.p); };
+	if (stage == 0) // world-space colliders (4 float4, the last one holds integers) + boxes
+	{
+		run(w.nc, w.colWorld.p, 4, 3, 3, nullptr); run(w.nc, w.aabbMin.p, 1, 1, 0, nullptr); run(w.nc, w.aabbMax.p, 1, 1, 0, nullptr);
+	}
+	else if (stage == 1) run(numPairs, w.manifolds.p, 6, 5, 4, w.dCounters.p + CTR_NUM_VALID); // 4 contact points with depth, the normal (its .w holds packed material bits)
+	else if (stage == 2) // rigid_body_global_state: centre of gravity + inverse mass, world inverse inertia, velocities
+	{
+		run(w.nb, w.cog.p, 1, 1, 1, nullptr); run(w.nb, w.invIw.p, 3, 3, 0, nullptr); run(w.nb, w.vel.p, 2, 2, 1, nullptr);
+	}
+	else if (stage == 3) { run(w.nb, w.pose.p, 2, 2, 2, nullptr); run(w.nb, w.vel.p, 2, 2, 1, nullptr); } // the step's result
+}

@@ -92,6 +92,7 @@ enum
 	CTR_CL_SHARED = 430,    // statistics: bodies handed between tasks (summed over tasks)
 	CTR_CL_PHASE_COUNT = 431,// 5 words: statistics: manifolds per phase
 	CTR_CL_BBOX = 436,      // 6 words: min xyz, max xyz of the simulated bodies' centres of gravity (order-preserving integer encoding)
+	CTR_VALIDATE = 448,     // 2 words: non-finite values found by the debug guard (MI_PHYSICS_VALIDATE=1), first offender (stage << 28 | index)
 	CTR_CL_REMAIN = 442,    // 6 words: manifolds still unassigned when partition phase p starts ([0] unused: all active ones)
 	CTR_WORDS = 512,
 };
@@ -173,6 +174,7 @@ struct World
 	u32 flowEagerMax = 131072;            // up to this many manifolds every poll fetches both record halves (MI_FLOW_EAGER)
 	u32 flowMaxManifolds = 0xFFFFFFFFu;   // the dataflow kernel takes the colours at the end of the schedule holding at most this many manifolds, launches the rest (MI_FLOW_MAX; default: everything)
 	// cluster sweep (k_cluster.hip)
+	bool validate = false;                // MI_PHYSICS_VALIDATE=1 / mi_enable_validation: NaN / Inf guard after every stage (the reference's VALIDATE macros, physics.cpp:807-926)
 	bool useCluster = true;               // MI_PHYSICS_NO_CLUSTER=1: launch-per-colour sweep only
 	bool lastStepCluster = false, backupVelocities = false;
 	u32 clusterParts = 3, clusterTaskWeight = 64u * 960u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
@@ -273,6 +275,7 @@ void launch_integrate_velocities(World& w, float dt);
 void launch_joint_init(World& w, float dt);
 void launch_joint_solve_iteration(World& w);
 void launch_and_mask(World& w);
+void launch_validate(World& w, u32 stage, u32 numPairs); // stage 0: world colliders + AABBs, 1: contacts, 2: body update records, 3: poses + velocities after the step
 void launch_copy_pose0(World& w);
 void launch_lerp_pose(World& w, float t);
 size_t primitives_temp_bytes(size_t maxItems);

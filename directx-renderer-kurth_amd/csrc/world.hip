@@ -48,6 +48,7 @@ World::World(int dev) : device(dev)
 	stageEvents.resize(STAGE_RING * 6);
 	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
 	useGraph = getenv("MI_PHYSICS_NO_GRAPH") == nullptr; // rocprofv3's kernel trace needs plain launches
+	validate = getenv("MI_PHYSICS_VALIDATE") != nullptr;
 	useCluster = getenv("MI_PHYSICS_NO_CLUSTER") == nullptr; // LDS cluster contact sweep (one launch) vs global colouring + one launch per colour
 	useFusedColoring = false;                                // the launch sweep colours with one launch per round (no grid barrier)
 	useWarmColoring = getenv("MI_PHYSICS_NO_WARM_COLORING") == nullptr;
@@ -614,6 +615,7 @@ void World::refreshCounters()
 	readCounters(*this);
 	if (!prevNumPairs) { memset(hCounters + CTR_KEY_START, 0, sizeof(u32) * (MI_NUM_SCHEDULE_KEYS + 1)); hCounters[CTR_NUM_MANIFOLDS] = 0; hCounters[CTR_NUM_VALID] = 0; hCounters[CTR_NUM_COLORS] = 0; }
 	hCounters[CTR_NUM_PAIRS] = prevTruePairs; // (the pair count of the finished step; the device word is the same until the next broadphase)
+	if (hCounters[CTR_VALIDATE]) fail(MI_ERR_INVALID_STATE, "non-finite values in the last step (debug guard): " + std::to_string(hCounters[CTR_VALIDATE]) + " elements, first code " + std::to_string(hCounters[CTR_VALIDATE + 1]));
 	countPreviousStep();
 }
 
@@ -636,6 +638,7 @@ int World::stepInternal(float dt, u32 iters)
 	}
 
 	launch_build_colliders(*this);
+	launch_validate(*this, 0, 0);
 	launch_broadphase_count(*this);
 	readCounters(*this);                                   // sync #1: number of overlapping pairs
 	if (hCounters[CTR_FLOW_STATUS])                        // the cluster sweep of the previous step gave up
@@ -647,6 +650,13 @@ int World::stepInternal(float dt, u32 iters)
 		readCounters(*this);
 	}
 	flowPending = false;
+	if (hCounters[CTR_VALIDATE])                           // the debug guard found NaN / Inf in the previous step (or in this step's colliders)
+	{
+		static const char* stageName[4] = { "world-space colliders / boxes", "contacts", "body update records (centre of gravity, inverse inertia, velocities)", "poses / velocities after the step" };
+		u32 first = hCounters[CTR_VALIDATE + 1];
+		fail(MI_ERR_INVALID_STATE, "non-finite values in " + std::string(stageName[(first >> 28) & 3u]) + ": " + std::to_string(hCounters[CTR_VALIDATE]) + " elements, first at index " + std::to_string(first & 0x0FFFFFFFu));
+		return lastError;
+	}
 	countPreviousStep();                                   // the counters just read hold the previous step's colour / contact counts
 	if (hCounters[CTR_TERRAIN_OVERFLOW]) { fail(MI_ERR_CAPACITY, "more terrain contacts than manifold slots: contacts were dropped (raise MI_TERRAIN_SLOTS_PER_COLLIDER)"); return lastError; }
 	const u32 truePairs = hCounters[CTR_NUM_PAIRS];
@@ -660,6 +670,7 @@ int World::stepInternal(float dt, u32 iters)
 	launch_narrowphase(*this, truePairs);
 	launch_heightmap(*this, truePairs, numPairs);          // physics.cpp:1236-1249
 	launch_trigger_events(*this);                          // physics.cpp:1255 (handleNonCollisionInteractions)
+	launch_validate(*this, 1, numPairs);
 	if (T) MI_CHECK(hipEventRecord(ev[2], stream));
 
 	launch_apply_fields(*this);                            // :963-967, :1273
@@ -670,6 +681,7 @@ int World::stepInternal(float dt, u32 iters)
 	backupVelocities = clusterStep;                        // pre-solve velocities, in case the cluster sweep has to be redone (World::recoverFlow)
 	if (clusterStep) velBackup.ensure(2 * ((size_t)nb + 1), stream);
 	launch_integrate_forces(*this, dt);
+	launch_validate(*this, 2, 0);
 	launch_collision_events(*this, numPairs);              // :1284 (handleCollisionCallbacks: after the force integration)
 	if (clusterStep)
 	{
@@ -692,6 +704,7 @@ int World::stepInternal(float dt, u32 iters)
 	if (T) MI_CHECK(hipEventRecord(ev[4], stream));
 
 	launch_integrate_velocities(*this, dt);
+	launch_validate(*this, 3, 0);
 	launch_cloth(*this, dt);                               // physics.cpp:1354-1358
 	if (T) MI_CHECK(hipEventRecord(ev[5], stream));
 
@@ -1033,7 +1046,8 @@ int mi_snapshot_save(mi_world* world, void* buffer, uint64_t capacity)
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	BlobWriter out; serialize(*W, out);
 	if (W->lastError) return W->lastError;
-	W->clusterSortDue = true; // the restored world orders its bodies at its first step: so does this one at its next
+	W->clusterSortDue = true; // the restored world orders its bodies at its first step: so does this one at its next ...
+	if (!W->clusterPartsFixed) W->clusterParts = 3; // ... and both start from the default number of partition phases
 	if (!buffer || capacity < out.bytes.size()) { W->fail(MI_ERR_CAPACITY, "mi_snapshot_save: buffer too small (ask mi_snapshot_size)"); return MI_ERR_CAPACITY; }
 	memcpy(buffer, out.bytes.data(), out.bytes.size());
 	return MI_OK;
@@ -1579,6 +1593,13 @@ uint32_t mi_add_slider_constraint_global(mi_world* world, uint32_t a, uint32_t b
 	return pushJoint(W, MI_CONSTRAINT_SLIDER, a, b, &c);
 }
 
+uint32_t mi_add_constraint(mi_world* world, uint32_t type, uint32_t a, uint32_t b, const void* pod)
+{
+	CHECK_WORLD(0xFFFFFFFFu);
+	if (type >= MI_JOINT_TYPES) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_add_constraint: unknown constraint type"); return 0xFFFFFFFFu; }
+	return pushJoint(W, type, a, b, pod);
+}
+
 int mi_constraint_get(mi_world* world, uint32_t type, uint32_t id, void* pod)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
@@ -1970,6 +1991,7 @@ int mi_get_stats(mi_world* world, mi_stats* out)
 	*out = st;
 	return W->lastError;
 }
+int mi_enable_validation(mi_world* world, int enable) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); W->validate = enable != 0; return MI_OK; }
 int mi_enable_stage_timing(mi_world* world, int enable) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); if (!enable) W->harvestTiming(); W->timeStages = enable != 0; return MI_OK; }
 uint32_t mi_num_bodies(mi_world* world) { CHECK_WORLD(0); return (u32)W->bodies.size(); }
 uint32_t mi_num_colliders(mi_world* world) { CHECK_WORLD(0); return (u32)W->colliders.size(); }

@@ -41,6 +41,15 @@ int main()
 			h->motorType = constraint_velocity_motor; h->motorVelocity = 0.5f; h->maxMotorTorque = 50.f;
 		}
 
+		// addConstraint(a, b, const T&) (physics.h:239-244), as the deserialisers call it: a second bob held by a ready-made distance constraint
+		auto bob2 = scene.createEntity("bob2");
+		bob2.addComponent<transform_component>(vec3(10.f, 4.f, 0.f), quat())
+			.addComponent<collider_component>(collider_component::asSphere(bounding_sphere{ vec3(0.f, 0.f, 0.f), 0.3f }, mat))
+			.addComponent<rigid_body_component>(false, 1.f);
+		distance_constraint rope{ vec3(0.f, 0.f, 0.f), vec3(0.f, 0.f, 0.f), 2.f };
+		auto ropeHandle = addConstraint(anchor, bob2, rope);
+		if (getConstraint(scene, ropeHandle)->globalLength != 2.f) std::abort();
+
 		// a global wind, an updraft box over the pile, and a trigger slab the boxes fall through (physics.h:182-203)
 		scene.createEntity("wind").addComponent<force_field_component>(vec3(0.5f, 0.f, 0.f));
 		scene.createEntity("updraft")

@@ -384,6 +384,19 @@ namespace mi
 	{ return { a.scene->checkId(mi_add_hinge_constraint_global(a.scene->world, a.body(), b.body(), &globalAnchor.x, &globalHingeAxis.x, minLimit, maxLimit), "addHingeConstraint") }; }
 	inline cone_twist_constraint_handle addConeTwistConstraintFromGlobalPoints(scene_entity& a, scene_entity& b, vec3 globalAnchor, vec3 globalAxis, float swingLimit, float twistLimit)
 	{ return { a.scene->checkId(mi_add_cone_twist_constraint_global(a.scene->world, a.body(), b.body(), &globalAnchor.x, &globalAxis.x, swingLimit, twistLimit), "addConeTwistConstraint") }; }
+	// addConstraint(a, b, const T&), physics.h:239-244: one overload per constraint POD (the reference's template, spelt out)
+	inline distance_constraint_handle addConstraint(scene_entity& a, scene_entity& b, const distance_constraint& c)
+	{ return { a.scene->checkId(mi_add_constraint(a.scene->world, MI_CONSTRAINT_DISTANCE, a.body(), b.body(), &c), "addConstraint") }; }
+	inline ball_constraint_handle addConstraint(scene_entity& a, scene_entity& b, const ball_constraint& c)
+	{ return { a.scene->checkId(mi_add_constraint(a.scene->world, MI_CONSTRAINT_BALL, a.body(), b.body(), &c), "addConstraint") }; }
+	inline fixed_constraint_handle addConstraint(scene_entity& a, scene_entity& b, const fixed_constraint& c)
+	{ return { a.scene->checkId(mi_add_constraint(a.scene->world, MI_CONSTRAINT_FIXED, a.body(), b.body(), &c), "addConstraint") }; }
+	inline hinge_constraint_handle addConstraint(scene_entity& a, scene_entity& b, const hinge_constraint& c)
+	{ return { a.scene->checkId(mi_add_constraint(a.scene->world, MI_CONSTRAINT_HINGE, a.body(), b.body(), &c), "addConstraint") }; }
+	inline cone_twist_constraint_handle addConstraint(scene_entity& a, scene_entity& b, const cone_twist_constraint& c)
+	{ return { a.scene->checkId(mi_add_constraint(a.scene->world, MI_CONSTRAINT_CONE_TWIST, a.body(), b.body(), &c), "addConstraint") }; }
+	inline slider_constraint_handle addConstraint(scene_entity& a, scene_entity& b, const slider_constraint& c)
+	{ return { a.scene->checkId(mi_add_constraint(a.scene->world, MI_CONSTRAINT_SLIDER, a.body(), b.body(), &c), "addConstraint") }; }
 	inline slider_constraint_handle addSliderConstraintFromGlobalPoints(scene_entity& a, scene_entity& b, vec3 globalAnchor, vec3 globalAxis, float minLimit = 1.f, float maxLimit = -1.f)
 	{ return { a.scene->checkId(mi_add_slider_constraint_global(a.scene->world, a.body(), b.body(), &globalAnchor.x, &globalAxis.x, minLimit, maxLimit), "addSliderConstraint") }; }
 

@@ -23,7 +23,7 @@ extern "C" {
 
 typedef struct mi_world mi_world;
 
-enum { MI_OK = 0, MI_ERR_NO_DEVICE = 1, MI_ERR_INVALID_ARGUMENT = 2, MI_ERR_HIP = 3, MI_ERR_CAPACITY = 4, MI_ERR_UNSUPPORTED = 5 };
+enum { MI_OK = 0, MI_ERR_NO_DEVICE = 1, MI_ERR_INVALID_ARGUMENT = 2, MI_ERR_HIP = 3, MI_ERR_CAPACITY = 4, MI_ERR_UNSUPPORTED = 5, MI_ERR_INVALID_STATE = 6 };
 
 /* collider_type, physics.h:58-70 — the enum order is load-bearing (pair kernels are bucketed by it). */
 enum { MI_COLLIDER_SPHERE = 0, MI_COLLIDER_CAPSULE = 1, MI_COLLIDER_CYLINDER = 2, MI_COLLIDER_AABB = 3, MI_COLLIDER_OBB = 4, MI_COLLIDER_HULL = 5 };
@@ -109,6 +109,10 @@ uint32_t mi_add_fixed_constraint_global(mi_world* w, uint32_t a, uint32_t b, con
 uint32_t mi_add_hinge_constraint_global(mi_world* w, uint32_t a, uint32_t b, const float globalAnchor[3], const float globalHingeAxis[3], float minLimit, float maxLimit);
 uint32_t mi_add_cone_twist_constraint_global(mi_world* w, uint32_t a, uint32_t b, const float globalAnchor[3], const float globalAxis[3], float swingLimit, float twistLimit);
 uint32_t mi_add_slider_constraint_global(mi_world* w, uint32_t a, uint32_t b, const float globalAnchor[3], const float globalAxis[3], float minLimit, float maxLimit);
+/* addConstraint(scene_entity& a, scene_entity& b, const T& c) for the six constraint types (physics.h:239-244): the constraint is given
+ * as the reference's POD (the layouts mi_constraint_get returns: 28/24/40/104/120/72 bytes), as the deserialisers hold it
+ * (serialization_binary.cpp:237-260).  type = MI_CONSTRAINT_*.  Returns the constraint id within its type, 0xFFFFFFFF on error. */
+uint32_t mi_add_constraint(mi_world* w, uint32_t type, uint32_t a, uint32_t b, const void* pod);
 
 /* T& getConstraint(scene, handle) (physics.h:248-253) as get/set of the POD whose layout is byte-identical to the reference's
  * distance/ball/fixed/hinge/cone_twist/slider_constraint structs (constraints.h:73-80,129-135,175-183,229-257,346-380,497-520;
@@ -211,6 +215,10 @@ int mi_read_transforms(mi_world* w, uint32_t which, float* out7, uint32_t n);
 int mi_read_velocities(mi_world* w, float* out6, uint32_t n);          /* n x {linear3, angular3} */
 int mi_read_mass_properties(mi_world* w, float* out13, uint32_t n);    /* n x {localCOG3, invMass, invInertia9 (column-major)} */
 int mi_get_stats(mi_world* w, mi_stats* out);
+/* Debug guard: the reference's VALIDATE macros (physics.cpp:807-926, compiled out there): with the guard on, every stage's output is
+ * scanned for NaN / Inf on the device and the step after the one that produced one fails with MI_ERR_INVALID_STATE (the message names
+ * the stage and the first offending element).  Also switched on by MI_PHYSICS_VALIDATE=1.  Costs a few small launches per step. */
+int mi_enable_validation(mi_world* w, int enable);
 int mi_enable_stage_timing(mi_world* w, int enable);
 uint32_t mi_num_bodies(mi_world* w);
 uint32_t mi_num_colliders(mi_world* w);

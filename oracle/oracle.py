@@ -286,6 +286,10 @@ class OracleWorld:
         """Custom-order contact solves in the device's row form (default) or with the reference formula."""
         self.lib.orc_set_row_form(self.w, int(on))
 
+    def set_wide_rsqrt(self, on=True):
+        """The 8-lane solver's noz with the host's rsqrtss estimate (the reference's AVX2 semantics) instead of exact 1/sqrt.  Process-wide."""
+        self.lib.orc_set_wide_rsqrt(int(on))
+
     def stage_seconds(self, reset=True):
         """Cumulative wall time per stage since the last reset: colliders + broadphase, narrowphase, forces + constraint setup, solve, integration."""
         out = np.zeros(5, np.float64)

@@ -4,14 +4,30 @@
 // per lane from the 104-byte AoS records, friction row then normal row, scattered back.  Written as plain
 // 8-wide loops that gcc vectorises under -O3 -mavx2 -mfma; this is the `cpu_baseline` ("port") that bench.py
 // times on the GPU box's host core.  Differences from the reference's wide math, all documented in DESIGN.md:
-//   * noz() uses exact 1/sqrtf instead of _mm256_rsqrt_ps (math_simd.h:283-289) — vendor-independent bits;
+//   * noz() uses exact 1/sqrtf instead of _mm256_rsqrt_ps (math_simd.h:283-289) — vendor-independent bits — unless
+//     wideApproxRsqrt() is switched on (orc_set_wide_rsqrt): then the host's own rsqrtss (12-bit estimate, no Newton step: what the
+//     reference's noz executes; its bits differ between CPU vendors) is used, so that the distance between "exact" and "AVX2
+//     semantics" can be reported (tests/test_oracle.py);
 //   * contact indices are u32 (reference truncates to u16 at constraints.cpp:3473).
 #pragma once
 #include "oconstraints.h"
 
+#if defined(__SSE__)
+#include <xmmintrin.h>
+#endif
+
 namespace orc {
 
 static const u32 WIDE = 8;
+inline bool& wideApproxRsqrt() { static bool on = false; return on; }
+static inline float rsqrtEstimate(float x)
+{
+#if defined(__SSE__)
+	return _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set_ss(x)));
+#else
+	return 1.f / sqrtf(x);
+#endif
+}
 
 // constraints.h:641-662 (30 float rows x 8 + 2 x 8 ids)
 struct alignas(32) simd_collision_constraint_batch
@@ -94,7 +110,7 @@ static inline void initializeCollisionBatchesWide(std::vector<simd_collision_con
 		{
 			float tx = rel.x[l] - nDotRel[l] * normal.x[l], ty = rel.y[l] - nDotRel[l] * normal.y[l], tz = rel.z[l] - nDotRel[l] * normal.z[l];
 			float sl = tx * tx + ty * ty + tz * tz;
-			float inv = (sl < 1e-8f) ? 0.f : (1.f / sqrtf(sl)); // noz, exact instead of rsqrt
+			float inv = (sl < 1e-8f) ? 0.f : (wideApproxRsqrt() ? rsqrtEstimate(sl) : (1.f / sqrtf(sl))); // noz (math_simd.h:283-289): exact, or the hardware estimate on request
 			tangent.x[l] = tx * inv; tangent.y[l] = ty * inv; tangent.z[l] = tz * inv;
 		}
 		wstore3(rA, batch.relGlobalAnchorA); wstore3(rB, batch.relGlobalAnchorB);

@@ -115,6 +115,7 @@ struct world
 	std::vector<u32> customOrder;
 	double stageSeconds[5] = { 0, 0, 0, 0, 0 }; // cumulative wall time per stage (colliders + broadphase, narrowphase, forces + constraint setup, solve, velocity integration): cpu_baseline's breakdown
 	bool rowForm = true; // custom-order solves use the device's row form (solveCollisionConstraintRowForm); false = the reference formula
+	bool scalarRowForm = false; // the scalar solver (emission order) in row form: lets tests bound row form vs reference formula on the same order
 	// "Follow" mode for whole-step parity with a device run: the narrowphase consumes an externally ordered candidate-pair list
 	// (slots) instead of prune/classify/bucket, contacts are solved manifold by manifold in `slotOrder`, joints in `jointOrder[t]`.
 	bool usePairOverride = false;
@@ -889,7 +890,8 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 		}
 		else
 		{
-			for (u32 i = 0; i < numContacts; ++i) solveCollisionConstraint(w.contactConstraints[i], w.contacts[i], w.contactBodyPairs[i], rbs);
+			if (w.scalarRowForm) { for (u32 i = 0; i < numContacts; ++i) solveCollisionConstraintRowForm(w.contactConstraints[i], w.contacts[i], w.contactBodyPairs[i], rbs); }
+			else for (u32 i = 0; i < numContacts; ++i) solveCollisionConstraint(w.contactConstraints[i], w.contacts[i], w.contactBodyPairs[i], rbs);
 		}
 	}
 
@@ -1451,7 +1453,8 @@ int orc_set_velocity(world* w, u32 b, const float* lin, const float* ang)
 int orc_step(world* w, float* timer, const physics_settings* settings, u32 mode, float dt) { physicsStep(*w, *timer, *settings, mode, dt); return 0; }
 int orc_step_internal(world* w, u32 iterations, u32 mode, float dt) { physicsStepInternal(*w, iterations, mode, dt); return 0; }
 void orc_set_custom_order(world* w, const u32* order, u32 n) { w->customOrder.assign(order, order + n); }
-void orc_set_row_form(world* w, int on) { w->rowForm = on != 0; }
+void orc_set_row_form(world* w, int on) { w->rowForm = on != 0; w->scalarRowForm = on != 0; }
+void orc_set_wide_rsqrt(int on) { wideApproxRsqrt() = on != 0; }
 void orc_stage_seconds(world* w, double* out5, int reset) { for (int i = 0; i < 5; ++i) { out5[i] = w->stageSeconds[i]; if (reset) w->stageSeconds[i] = 0; } }
 // Follow mode (see struct world): ordered candidate pairs + manifold execution order; n = 0 switches it off.
 void orc_set_follow(world* w, const u32* pairs2, u32 numPairs, const u32* slotOrder, u32 numOrder)

@@ -73,3 +73,23 @@ def test_delete_all_constraints_from_body(mi):
     for _ in range(60):
         g.step_internal(scene.dt)
     assert np.isfinite(g.transforms(1)).all()
+
+
+def test_validation_guard_reports_non_finite_state(mi):
+    """The debug guard (mi_enable_validation / MI_PHYSICS_VALIDATE=1; the reference's VALIDATE macros, physics.cpp:807-926): a NaN
+    written into a body's velocity is found after the force integration and the next step fails with MI_ERR_INVALID_STATE naming the
+    stage; without the guard the same world steps on (NaN in, NaN out, as in the reference)."""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name("c1")
+    w = scene.instantiate(mi.World())
+    w.enable_validation(True)
+    for _ in range(5):
+        w.step_internal(scene.dt)
+    w.synchronize()
+    t, v = w.transforms(1), w.velocities()
+    v[3, 1] = np.nan
+    w.write_state(t, v)
+    w.step_internal(scene.dt)                    # produces the NaN records; the guard's verdict is read at the next synchronisation
+    with pytest.raises(mi.PhysicsError, match="non-finite"):
+        w.step_internal(scene.dt)
+        w.stats()
