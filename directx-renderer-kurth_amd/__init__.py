@@ -74,7 +74,7 @@ EXPORTED_SYMBOLS = [
     "mi_add_cloth", "mi_cloth_set_fixed_vertices", "mi_cloth_set_properties", "mi_set_cloth_iterations", "mi_num_cloths", "mi_cloth_num_particles", "mi_cloth_read",
     "mi_test_physics_interaction", "mi_apply_force_torque", "mi_set_velocity",
     "mi_set_transform", "mi_write_transforms", "mi_write_velocities", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
-    "mi_get_stats", "mi_enable_validation", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_debug_num_pairs", "mi_debug_read_pairs",
+    "mi_get_stats", "mi_enable_validation", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_slab_configure", "mi_slab_message_bytes", "mi_slab_pack", "mi_slab_unpack", "mi_slab_read_codes", "mi_debug_num_pairs", "mi_debug_read_pairs",
     "mi_debug_read_world_colliders", "mi_debug_num_manifold_slots", "mi_debug_read_manifolds", "mi_debug_num_colors", "mi_debug_read_schedule",
     "mi_debug_read_joint_order", "mi_debug_read_body_state", "mi_debug_flow_trace",
 ]
@@ -116,6 +116,7 @@ def load_library():
         lib.mi_world_create.restype = C.c_void_p
         lib.mi_world_restore.restype = C.c_void_p
         lib.mi_snapshot_size.restype = C.c_uint64
+        lib.mi_slab_message_bytes.restype = C.c_uint64
         lib.mi_last_error.restype = C.c_char_p
         lib.mi_heightmap_height_at.restype = C.c_float
         for name in EXPORTED_SYMBOLS:
@@ -397,6 +398,25 @@ class World:
         """Debug guard: NaN / Inf scan after every stage (the reference's VALIDATE macros, physics.cpp:807-926); a step after one that
         produced a non-finite value fails."""
         self._check(self.lib.mi_enable_validation(self.w, int(on)))
+
+    # ---- spatial slab halo (device side) -------------------------------------------------------------------
+    def slab_configure(self, rank, size, axis, lo, hi, margin):
+        self._check(self.lib.mi_slab_configure(self.w, C.c_uint32(rank), C.c_uint32(size), C.c_uint32(axis), C.c_float(lo), C.c_float(hi), C.c_float(margin)))
+
+    def slab_message_bytes(self, capacity):
+        return int(self.lib.mi_slab_message_bytes(C.c_uint32(capacity)))
+
+    def slab_pack(self, left_ptr, right_ptr, capacity):
+        """left_ptr / right_ptr: device addresses (int) of message buffers, or 0 for a missing neighbour."""
+        self._check(self.lib.mi_slab_pack(self.w, C.c_void_p(left_ptr or None), C.c_void_p(right_ptr or None), C.c_uint32(capacity)))
+
+    def slab_unpack(self, left_ptr, right_ptr, capacity):
+        self._check(self.lib.mi_slab_unpack(self.w, C.c_void_p(left_ptr or None), C.c_void_p(right_ptr or None), C.c_uint32(capacity)))
+
+    def slab_codes(self):
+        out = np.zeros(self.num_bodies, np.uint8)
+        self._check(self.lib.mi_slab_read_codes(self.w, _p(out), C.c_uint32(len(out))))
+        return out
 
     def stats(self):
         s = Stats()

@@ -309,3 +309,100 @@ void launch_validate(World& w, u32 stage, u32 numPairs)
 	}
 	else if (stage == 3) { run(w.nb, w.pose.p, 2, 2, 2, nullptr); run(w.nb, w.vel.p, 2, 2, 1, nullptr); } // the step's result
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Spatial slabs: ghost-body halo on the device (mi_slab_*; design: DESIGN.md section 5).  Message = uint4 header {count, dropped, 0, 0}
+// + records of 72 B {index, flag, pose 2 x float4, vel 2 x float4}, written as 18 dwords.
+// ---------------------------------------------------------------------------------------------------------------
+#define SLAB_RECORD_DWORDS 18u
+MI_DEV float slabCoord(float4 p, u32 axis) { return axis == 0u ? p.x : (axis == 1u ? p.y : p.z); }
+
+__global__ void __launch_bounds__(256) k_slab_classify(u32 nb, u32 axis, float lo, float hi, float margin, const float4* __restrict__ pose, const uint8_t* __restrict__ alive,
+	uint8_t* __restrict__ code, uint8_t* __restrict__ simMask, u32* __restrict__ fresh)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nb) return;
+	float x = slabCoord(pose[2 * i], axis);
+	uint8_t c = MI_SLAB_INACTIVE;
+	if (x >= lo && x < hi) c = MI_SLAB_OWNED;
+	else if (x >= hi && x < hi + margin) c = MI_SLAB_GHOST_RIGHT; // what the neighbours would send in their first exchange
+	else if (x < lo && x >= lo - margin) c = MI_SLAB_GHOST_LEFT;
+	code[i] = c; fresh[i] = 0u;
+	simMask[i] = (c != MI_SLAB_INACTIVE && alive[i]) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_slab_pack(u32 nb, u32 axis, float lo, float hi, float margin, u32 capacity, u32 stamp, const float4* __restrict__ pose, const float4* __restrict__ vel,
+	const uint8_t* __restrict__ alive, uint8_t* __restrict__ code, u32* __restrict__ fresh, u32* __restrict__ msgLeft, u32* __restrict__ msgRight)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nb || code[i] != MI_SLAB_OWNED || !alive[i]) return;
+	float x = slabCoord(pose[2 * i], axis);
+	for (u32 side = 0; side < 2; ++side)
+	{
+		u32* msg = side ? msgRight : msgLeft;
+		if (!msg) continue;
+		bool band = side ? (x >= hi - margin) : (x < lo + margin);
+		if (!band) continue;
+		bool migrate = side ? (x >= hi) : (x < lo);
+		u32 slot = atomicAdd(&msg[0], 1u);
+		if (slot >= capacity) { atomicAdd(&msg[1], 1u); continue; } // dropped: the host sees it in the header it receives back / sends on
+		u32* r = msg + 4u + slot * SLAB_RECORD_DWORDS;
+		r[0] = i; r[1] = migrate ? MI_SLAB_MIGRATE : MI_SLAB_GHOST;
+		float4 p0 = pose[2 * i], p1 = pose[2 * i + 1], v0 = vel[2 * i], v1 = vel[2 * i + 1];
+		r[2] = __float_as_uint(p0.x); r[3] = __float_as_uint(p0.y); r[4] = __float_as_uint(p0.z); r[5] = __float_as_uint(p0.w);
+		r[6] = __float_as_uint(p1.x); r[7] = __float_as_uint(p1.y); r[8] = __float_as_uint(p1.z); r[9] = __float_as_uint(p1.w);
+		r[10] = __float_as_uint(v0.x); r[11] = __float_as_uint(v0.y); r[12] = __float_as_uint(v0.z); r[13] = __float_as_uint(v0.w);
+		r[14] = __float_as_uint(v1.x); r[15] = __float_as_uint(v1.y); r[16] = __float_as_uint(v1.z); r[17] = __float_as_uint(v1.w);
+		if (migrate) { code[i] = side ? MI_SLAB_GHOST_RIGHT : MI_SLAB_GHOST_LEFT; fresh[i] = stamp; } // its state here is the freshest there is: keep it as a ghost this step
+	}
+}
+
+__global__ void __launch_bounds__(256) k_slab_apply(u32 nb, u32 capacity, u32 stamp, uint8_t ghostCode, const u32* __restrict__ msg, float4* __restrict__ pose, float4* __restrict__ pose0,
+	float4* __restrict__ poseLerp, float4* __restrict__ vel, uint8_t* __restrict__ code, u32* __restrict__ fresh)
+{
+	u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+	u32 count = min(msg[0], capacity);
+	if (k >= count) return;
+	const u32* r = msg + 4u + k * SLAB_RECORD_DWORDS;
+	u32 i = r[0];
+	if (i >= nb) return; // a corrupt record must not become a wild write
+	float4 p0 = make_float4(__uint_as_float(r[2]), __uint_as_float(r[3]), __uint_as_float(r[4]), __uint_as_float(r[5]));
+	float4 p1 = make_float4(__uint_as_float(r[6]), __uint_as_float(r[7]), __uint_as_float(r[8]), __uint_as_float(r[9]));
+	pose[2 * i] = p0; pose[2 * i + 1] = p1; pose0[2 * i] = p0; pose0[2 * i + 1] = p1; poseLerp[2 * i] = p0; poseLerp[2 * i + 1] = p1;
+	vel[2 * i] = make_float4(__uint_as_float(r[10]), __uint_as_float(r[11]), __uint_as_float(r[12]), __uint_as_float(r[13]));
+	vel[2 * i + 1] = make_float4(__uint_as_float(r[14]), __uint_as_float(r[15]), __uint_as_float(r[16]), __uint_as_float(r[17]));
+	code[i] = (r[1] == MI_SLAB_MIGRATE) ? (uint8_t)MI_SLAB_OWNED : ghostCode;
+	fresh[i] = stamp;
+}
+
+// Ghosts the neighbour did not send this step have left its band: inactive.  The simulate mask follows the codes.
+__global__ void __launch_bounds__(256) k_slab_retire(u32 nb, u32 stamp, bool haveLeft, bool haveRight, const uint8_t* __restrict__ alive, uint8_t* __restrict__ code, const u32* __restrict__ fresh, uint8_t* __restrict__ simMask)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nb) return;
+	uint8_t c = code[i];
+	if (((c == MI_SLAB_GHOST_LEFT && haveLeft) || (c == MI_SLAB_GHOST_RIGHT && haveRight)) && fresh[i] != stamp) { c = MI_SLAB_INACTIVE; code[i] = c; }
+	simMask[i] = (c != MI_SLAB_INACTIVE && alive[i]) ? 1 : 0;
+}
+
+void launch_slab_classify(World& w)
+{
+	if (!w.nb) return;
+	hipLaunchKernelGGL(k_slab_classify, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, w.slabAxis, w.slabLo, w.slabHi, w.slabMargin, w.pose.p, w.aliveMask.p, w.slabCode.p, w.simMask.p, w.slabFresh.p);
+}
+void launch_slab_pack(World& w, void* left, void* right, u32 capacity)
+{
+	if (!w.nb) return;
+	if (left) MI_CHECK(hipMemsetAsync(left, 0, 16, w.stream));
+	if (right) MI_CHECK(hipMemsetAsync(right, 0, 16, w.stream));
+	hipLaunchKernelGGL(k_slab_pack, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, w.slabAxis, w.slabLo, w.slabHi, w.slabMargin, capacity, w.slabStamp, w.pose.p, w.vel.p,
+		w.aliveMask.p, w.slabCode.p, w.slabFresh.p, (u32*)left, (u32*)right);
+}
+void launch_slab_unpack(World& w, const void* left, const void* right, u32 capacity)
+{
+	if (!w.nb) return;
+	dim3 grid((capacity + 255) / 256), block(256);
+	if (left && capacity) hipLaunchKernelGGL(k_slab_apply, grid, block, 0, w.stream, w.nb, capacity, w.slabStamp, (uint8_t)MI_SLAB_GHOST_LEFT, (const u32*)left, w.pose.p, w.pose0.p, w.poseLerp.p, w.vel.p, w.slabCode.p, w.slabFresh.p);
+	if (right && capacity) hipLaunchKernelGGL(k_slab_apply, grid, block, 0, w.stream, w.nb, capacity, w.slabStamp, (uint8_t)MI_SLAB_GHOST_RIGHT, (const u32*)right, w.pose.p, w.pose0.p, w.poseLerp.p, w.vel.p, w.slabCode.p, w.slabFresh.p);
+	hipLaunchKernelGGL(k_slab_retire, dim3((w.nb + 255) / 256), block, 0, w.stream, w.nb, w.slabStamp, left != nullptr, right != nullptr, w.aliveMask.p, w.slabCode.p, w.slabFresh.p, w.simMask.p);
+}

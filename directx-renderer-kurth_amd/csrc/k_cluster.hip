@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) k_cl_ranks(u32 nb, u32 numParts, const u3
 // first and gather in the low colours: a colour's sweep time is that of its longest manifold, and this keeps the 2-4-contact ones
 // (20 % of a mixed pile) out of most colours.  Then a pseudo-random priority (hash of the narrowphase slot and the round), then
 // the position inside the task, which makes the bid unique.
-MI_DEV u32 clBid(u32 slot, u32 count, u32 round, u32 i) { return ((4u - count) << 30) | ((clHash(slot * 2654435761u + round) & 0x3FFFFu) << 12) | i; }
+MI_DEV u32 clBid(u32 slot, u32 count, u32 round, u32 i) { return (((4u - count) & 3u) << 22) | ((clHash(slot * 2654435761u + round) & 0x3FFu) << 12) | (i & 0xFFFu); } // 24 bits
 #define CL_SUBCOUNTERS 8u // a task's append cursor is split in 8 (by workgroup) so that ~650 returning atomics do not queue on one address
 
 // Everything the assignment accumulates into, cleared in one launch.
@@ -185,8 +185,9 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 		u32 ph = key / CL_MAX_TASKS;
 		taskKey[j] = key;
 		taskPos[j] = atomicAdd(&taskCount[key * CL_SUBCOUNTERS + (blockIdx.x & (CL_SUBCOUNTERS - 1u))], 1u);
-		if (da) atomicOr(&phaseMask[ids.x], 1u << ph);
-		if (db) atomicOr(&phaseMask[ids.y], 1u << ph);
+		// (most bodies have the bit already from another manifold of theirs: look before the atomic)
+		if (da && !(__hip_atomic_load(&phaseMask[ids.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << ph))) atomicOr(&phaseMask[ids.x], 1u << ph);
+		if (db && !(__hip_atomic_load(&phaseMask[ids.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << ph))) atomicOr(&phaseMask[ids.y], 1u << ph);
 	}
 	else
 	{
@@ -265,7 +266,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 	u32* mCnt = mPos + CL_TASK_MAX_MANIFOLDS;           // [..] contact count by final position, then its exclusive scan of (count - 1)
 	u32* mSlot = mCnt + CL_TASK_MAX_MANIFOLDS;          // [..] narrowphase slot | contacts << 28 (the colouring rounds' priorities hash it)
 	u32* hist = mSlot + CL_TASK_MAX_MANIFOLDS;          // [264] per key, then cursors
-	__shared__ u32 sNumShared, sNumPrivate, sLeft, sMaxColor, sScan[16], sSharedBase;
+	__shared__ u32 sNumShared, sNumPrivate, sLeftA, sLeftB, sMaxColor, sScan[16], sSharedBase;
 	const u32 tid = threadIdx.x;
 	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
 
@@ -344,18 +345,24 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			mSlot[i] = (ids.w & 0x0FFFFFFFu) | (ids.z << 28);
 		}
 		__syncthreads();
-		// 3. colouring rounds
+		// 3. colouring rounds.  A claim word holds {round, inverted bid}: a later round's bid beats any earlier one under atomicMax, so
+		// the claims need no clearing between rounds: two barriers per round (bid | decide).  The two sLeft counters alternate by round
+		// parity so that the next round's reset cannot overtake this round's readers.
+		for (u32 l = tid; l < numBodies; l += CL_LANES) claim[l] = 0u;
+		if (tid == 0) { sLeftA = 0; sLeftB = 0; }
+		__syncthreads();
 		for (u32 round = 0; ; ++round)
 		{
-			if (tid == 0) sLeft = 0;
+			u32* leftNow = (round & 1u) ? &sLeftB : &sLeftA;
+			const bool lastRound = round >= 254u; // (the round tag has 8 bits: whoever is still uncoloured then goes to the serial tail)
 			for (u32 i = tid; i < n; i += CL_LANES)
 			{
 				if (mKey[i] != 0xFFFFFFFFu) continue;
 				u32 sc = mSlot[i];
-				u32 bid = clBid(sc & 0x0FFFFFFFu, sc >> 28, round, i);
+				u32 bid = ((round + 1u) << 24) | (0xFFFFFFu - clBid(sc & 0x0FFFFFFFu, sc >> 28, round, i));
 				u32 ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16;
-				if (la != CL_LOCAL_STATIC) atomicMin(&claim[la], bid);
-				if (lb != CL_LOCAL_STATIC) atomicMin(&claim[lb], bid);
+				if (la != CL_LOCAL_STATIC) atomicMax(&claim[la], bid);
+				if (lb != CL_LOCAL_STATIC) atomicMax(&claim[lb], bid);
 			}
 			__syncthreads();
 			u32 left = 0;
@@ -363,12 +370,12 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			{
 				if (mKey[i] != 0xFFFFFFFFu) continue;
 				u32 sc = mSlot[i], cnt = sc >> 28;
-				u32 bid = clBid(sc & 0x0FFFFFFFu, cnt, round, i);
+				u32 bid = ((round + 1u) << 24) | (0xFFFFFFu - clBid(sc & 0x0FFFFFFFu, cnt, round, i));
 				u32 ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16;
 				bool won = (la == CL_LOCAL_STATIC || claim[la] == bid) && (lb == CL_LOCAL_STATIC || claim[lb] == bid);
-				if (!won) { ++left; continue; }
+				if (!won && !lastRound) { ++left; continue; }
 				u64 used = (la != CL_LOCAL_STATIC ? mask[la] : 0ull) | (lb != CL_LOCAL_STATIC ? mask[lb] : 0ull);
-				u32 c = (~used) ? (u32)__ffsll((long long)~used) - 1u : CL_SERIAL_COLOR;
+				u32 c = (won && ~used) ? (u32)__ffsll((long long)~used) - 1u : CL_SERIAL_COLOR;
 				if (c < CL_SERIAL_COLOR)
 				{
 					if (la != CL_LOCAL_STATIC) mask[la] |= 1ull << c; // the only winner on this body in this round
@@ -377,13 +384,12 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 				}
 				mKey[i] = c * 4u + (4u - cnt);
 			}
-			if (left) atomicAdd(&sLeft, left);
+			if (left) atomicAdd(leftNow, left);
+			if (tid == 0) *((round & 1u) ? &sLeftA : &sLeftB) = 0; // the other counter: next round's
 			__syncthreads();
-			for (u32 l = tid; l < numBodies; l += CL_LANES) claim[l] = 0xFFFFFFFFu;
-			bool done = sLeft == 0u;
-			__syncthreads();
-			if (done) break;
+			if (*leftNow == 0u) break;
 		}
+		__syncthreads();
 		// 4. order by key: histogram, scan by one wave, cursors
 		for (u32 i = tid; i < n; i += CL_LANES) atomicAdd(&hist[mKey[i]], 1u);
 		__syncthreads();

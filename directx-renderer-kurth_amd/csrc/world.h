@@ -155,6 +155,8 @@ struct World
 	DevBuf<float4> hullVerts, hullInfo;   // all hull vertices (xyz); per geometry {aabbMin.xyz, firstVertex}, {aabbMax.xyz, vertexCount}
 	DevBuf<uint8_t> aliveMask;            // per body: 0 = deleted (mi_delete_body); ANDed into every simulate mask handed in
 	DevBuf<uint8_t> simMask;              // per body: 1 = simulated here (owned or ghost), 0 = lives on another GPU's slab
+	// spatial slab (mi_slab_*): ownership code per body, stamp of the last refresh of a ghost, this rank's interval
+	DevBuf<uint8_t> slabCode; DevBuf<u32> slabFresh; u32 slabRank = 0, slabSize = 0, slabAxis = 0, slabStamp = 0; float slabLo = 0.f, slabHi = 0.f, slabMargin = 0.f;
 	// broadphase
 	DevBuf<u32> hashKey, hashKeySorted, sortIdx, sortIdxSorted, cellStart, cellEnd, largeFlag, largeScan, largeList, pairCount, pairOffset;
 	DevBuf<u64> sCellKey; DevBuf<float4> sMin, sMax;
@@ -275,6 +277,9 @@ void launch_integrate_velocities(World& w, float dt);
 void launch_joint_init(World& w, float dt);
 void launch_joint_solve_iteration(World& w);
 void launch_and_mask(World& w);
+void launch_slab_classify(World& w);
+void launch_slab_pack(World& w, void* left, void* right, u32 capacity);
+void launch_slab_unpack(World& w, const void* left, const void* right, u32 capacity);
 void launch_validate(World& w, u32 stage, u32 numPairs); // stage 0: world colliders + AABBs, 1: contacts, 2: body update records, 3: poses + velocities after the step
 void launch_copy_pose0(World& w);
 void launch_lerp_pose(World& w, float t);

@@ -2034,6 +2034,49 @@ int mi_state_from_device_buffers(mi_world* world, const void* dPose, const void*
 }
 
 // ---- inspection ----
+// ---- spatial slab halo (device side; the exchange of the messages is the caller's: RCCL send/recv on the world's stream) ----
+int mi_slab_configure(mi_world* world, uint32_t rank, uint32_t size, uint32_t axis, float lo, float hi, float margin)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (!size || rank >= size || axis > 2 || !(lo < hi) || !(margin >= 0.f)) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_slab_configure: bad slab"); return W->lastError; }
+	W->resolvePendingFlow();
+	W->upload();
+	if (W->lastError) return W->lastError;
+	W->slabRank = rank; W->slabSize = size; W->slabAxis = axis; W->slabLo = lo; W->slabHi = hi; W->slabMargin = margin; W->slabStamp = 0;
+	W->slabCode.ensure((size_t)W->nb + 1, W->stream); W->slabFresh.ensure((size_t)W->nb + 1, W->stream);
+	if (W->lastError) return W->lastError;
+	launch_slab_classify(*W);
+	W->clusterSortDue = true;
+	return W->lastError;
+}
+uint64_t mi_slab_message_bytes(uint32_t capacity) { return 16ull + 72ull * capacity; }
+int mi_slab_pack(mi_world* world, void* dMessageLeft, void* dMessageRight, uint32_t capacity)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (!W->slabSize || W->topologyDirty || W->slabCode.cap < (size_t)W->nb) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_slab_pack: configure the slab after the last add call"); return W->lastError; }
+	// (a give-up of the previous step's cluster sweep is settled first: the message must carry that step's real result)
+	W->resolvePendingFlow();
+	W->slabStamp++;
+	launch_slab_pack(*W, dMessageLeft, dMessageRight, capacity);
+	return W->lastError;
+}
+int mi_slab_unpack(mi_world* world, const void* dMessageLeft, const void* dMessageRight, uint32_t capacity)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (!W->slabSize || W->topologyDirty) { W->fail(MI_ERR_INVALID_ARGUMENT, "mi_slab_unpack: configure the slab after the last add call"); return W->lastError; }
+	launch_slab_unpack(*W, dMessageLeft, dMessageRight, capacity);
+	return W->lastError;
+}
+int mi_slab_read_codes(mi_world* world, uint8_t* outCodes, uint32_t n)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	if (!W->slabSize) return MI_ERR_INVALID_ARGUMENT;
+	n = std::min<u32>(n, W->nb);
+	MI_CHECK(hipMemcpyAsync(outCodes, W->slabCode.p, n, hipMemcpyDeviceToHost, W->stream));
+	MI_CHECK(hipStreamSynchronize(W->stream));
+	return W->lastError;
+}
+
 static void d2h(World* w, void* dst, const void* src, size_t bytes)
 {
 	w->resolvePendingFlow();

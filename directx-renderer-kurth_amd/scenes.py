@@ -752,7 +752,29 @@ def joints_mix():
     return s
 
 
+def rest_stacks(stacks=16, height=5):
+    """Things that come to REST and stay there: stacks of axis-aligned boxes (one box wide, `height` high, dropped from 1 mm above
+    each other) and single spheres and capsules lying on the ground.  Unlike a pile or a lattice of spheres, which topple and roll
+    (two Gauss-Seidel orders put their bodies metres apart), a resting stack has one equilibrium: the invariants of SURVEY section
+    8(c) — resting height within 1 mm, penetration within 1 mm — are meaningful here."""
+    s = Scene("rest_stacks_%d" % stacks, dt=1.0 / 120.0)
+    _ground(s, 40.0)
+    side = int(np.ceil(np.sqrt(stacks)))
+    for k in range(stacks):
+        x, z = 3.0 * (k % side) - 1.5 * side, 3.0 * (k // side) - 1.5 * side
+        for level in range(height):
+            b = s.add_body((x, 0.5 + 0.001 + level * 1.001, z))
+            s.add_collider(b, OBB, (0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.5, 0.5, 0.5), DEFAULT_MATERIAL)
+        b = s.add_body((x + 1.5, 0.301, z))
+        s.add_collider(b, SPHERE, (0.0, 0.0, 0.0, 0.3), DEFAULT_MATERIAL)
+        b = s.add_body((x, 0.251, z + 1.5))
+        s.add_collider(b, CAPSULE, (-0.4, 0.0, 0.0, 0.4, 0.0, 0.0, 0.25), DEFAULT_MATERIAL)
+    return s
+
+
 def by_name(name):
+    if name == "rest_stacks":
+        return rest_stacks()
     if name == "joints_mix":
         return joints_mix()
     if name == "c1":

@@ -235,6 +235,26 @@ int mi_device_pointers(mi_world* w, void** pose, void** vel, void** stream);
 int mi_state_to_device_buffers(mi_world* w, void* dPose, void* dVel);
 int mi_state_from_device_buffers(mi_world* w, const void* dPose, const void* dVel, const uint8_t* dMask);
 
+/* Ghost-body halo of a spatial slab, on the device (the reference has no counterpart).  mi_slab_configure makes this
+ * world rank `rank` of `size` slabs along `axis` owning [lo, hi) (use -/+INFINITY at the ends) with ghosts within `margin` of a cut,
+ * and classifies every body from its current pose (owned / ghost of the left or right neighbour / inactive).  Once per step, before
+ * mi_step_internal:
+ *   mi_slab_pack    one kernel: every owned body within `margin` of a cut goes into that neighbour's message; one that has crossed
+ *                   the cut goes with MI_SLAB_MIGRATE and becomes a ghost here.  A message is a caller-owned DEVICE buffer of
+ *                   mi_slab_message_bytes(capacity) bytes: a 16-byte header {count, dropped, 0, 0} + `capacity` records of 72 bytes
+ *                   {body index, flag, pose 2 x float4, velocity 2 x float4}.  Fixed capacity: no size round trip; `dropped` != 0
+ *                   means the band held more bodies than records (raise the capacity).  Pass NULL for a missing neighbour.
+ *   (the caller exchanges the messages: one send + one receive per neighbour, e.g. RCCL over xGMI, on the stream of mi_device_pointers)
+ *   mi_slab_unpack  two kernels: the received bodies are written (owner if MI_SLAB_MIGRATE, else ghost), ghosts the neighbour no longer
+ *                   sends go inactive, the simulate mask follows.
+ * Nothing here synchronises with the host.  mi_slab_read_codes copies the per-body codes out (tests / assembling results). */
+enum { MI_SLAB_INACTIVE = 0, MI_SLAB_OWNED = 1, MI_SLAB_GHOST_LEFT = 2, MI_SLAB_GHOST_RIGHT = 3, MI_SLAB_GHOST = 0, MI_SLAB_MIGRATE = 1 };
+int mi_slab_configure(mi_world* w, uint32_t rank, uint32_t size, uint32_t axis, float lo, float hi, float margin);
+uint64_t mi_slab_message_bytes(uint32_t capacity);
+int mi_slab_pack(mi_world* w, void* dMessageLeft, void* dMessageRight, uint32_t capacity);
+int mi_slab_unpack(mi_world* w, const void* dMessageLeft, const void* dMessageRight, uint32_t capacity);
+int mi_slab_read_codes(mi_world* w, uint8_t* outCodes, uint32_t n);
+
 /* ---- inspection of the last internal step (parity tests; mirrors the arrays of physics.cpp:1207-1228) ---------------- */
 uint32_t mi_debug_num_pairs(mi_world* w);
 int mi_debug_read_pairs(mi_world* w, uint32_t* outPairs2);                              /* broadphase overlaps, (A,B) collider indices */

@@ -38,8 +38,20 @@ def own_narrowphase_check(orc_world, o_pairs, slots, g_counts, tie_pairs=None):
     keep = ((ta == RIGID) | (tb == RIGID)) & ~((ta == RIGID) & (tb == RIGID) & (ia == ib))       # :2358-2369
     keep &= ((ta == RIGID) & (tb == RIGID)) | (ta == STATIC) | (tb == STATIC)                      # collisions only (:2378-2379)
     p = p[keep]
-    swap = cols["type"][p[:, 0]] > cols["type"][p[:, 1]]                                          # typeA <= typeB (:2374)
+    swap = cols["type"][p[:, 0]] >= cols["type"][p[:, 1]]                                         # typeA < typeB or swapped (:2374: equal types are swapped too)
     p[swap] = p[swap][:, ::-1]
+    # Equal-type pairs: the device keeps its grid's order where the reference has its sweep's order swapped (documented deviation;
+    # follow mode hands the oracle the device's order).  A pair that touches at zero depth can collide seen from one side and not
+    # from the other (GJK start direction, SAT axis order), so every candidate the device also has is tested in the device's order:
+    # what remains different is pruning, not orientation.
+    sl = np.asarray(slots, np.int64).reshape(-1, 2)
+    dev_key = (np.maximum(sl[:, 0], sl[:, 1]) << 32) | np.minimum(sl[:, 0], sl[:, 1])
+    order = np.argsort(dev_key)
+    own_key = (np.maximum(p[:, 0], p[:, 1]) << 32) | np.minimum(p[:, 0], p[:, 1])
+    pos = np.clip(np.searchsorted(dev_key[order], own_key), 0, max(len(order) - 1, 0))
+    if len(order):
+        hit = dev_key[order][pos] == own_key
+        p[hit] = sl[order][pos][hit]
     orc_world.use_hull_geometries()
     _, counts = orc.narrowphase_ordered(cols, p.astype(np.uint32))
     own = pair_set(p[counts > 0]); dev = pair_set(np.asarray(slots)[np.asarray(g_counts) > 0])
