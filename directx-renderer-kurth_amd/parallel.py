@@ -13,7 +13,9 @@ The reference is a single process with no notion of this (SURVEY.md §5, §8e); 
 * Contacts between an owned and a ghost body are generated and solved on both ranks from identical inputs; ghost results are
   discarded at the next exchange (block-Jacobi coupling across the cut, Gauss-Seidel inside a slab).
 
-`HaloExchanger` is pure torch (CPU tensors + gloo in the tests, CUDA tensors + nccl on the GPUs); `SlabWorld` binds it to the HIP world.
+`SlabWorld` is the product path: the halo is packed and applied by HIP kernels inside the world (mi_slab_pack / mi_slab_unpack), torch only
+moves the fixed-capacity messages.  `HaloExchanger` is the same protocol's bookkeeping written with torch tensors: the model the CPU
+tests run with gloo (world_size 2 and 3, no GPU) and the device kernels are compared with (tests/test_gpu_slabs.py).
 """
 import numpy as np
 import torch
@@ -125,34 +127,79 @@ class HaloExchanger:
         return pose, vel, code
 
 
-class SlabWorld:
-    """One HIP world per rank; same interface subset as `World` for bench.py (step_internal / stats / synchronize / transforms)."""
+def max_variance_axis(positions):
+    """The axis the reference's sweep would sort on: largest variance of the centres (collision_broad.cpp:374-376, 443-444)."""
+    return int(np.argmax(np.var(np.asarray(positions, np.float64), axis=0)))
 
-    def __init__(self, scene, device, rank, world_size, axis=0, margin=3.0, comm_on_cpu=False):
+
+class SlabWorld:
+    """One HIP world per rank; same interface subset as `World` for bench.py (step_internal / stats / synchronize / transforms).
+
+    The halo runs on the device (mi_slab_pack / mi_slab_unpack, include/mi_physics.h): per step ONE pack kernel fills a
+    fixed-capacity message per neighbour (count in its header: no size round trip), ONE batch of point-to-point sends / receives
+    moves them (RCCL over xGMI, enqueued on the world's own stream: the host does not wait for it), two small kernels apply what
+    arrived.  No host synchronisation is added to the step's own one.  `comm_on_cpu` (gloo rehearsals of several ranks on one GPU)
+    stages the messages through host memory instead, which does synchronise.
+    The slabs are cut along the axis of largest variance of the initial positions, at body-count quantiles; the cuts stay where
+    they are (no re-cut: a pile that flows far from its start unbalances the slabs, it does not break them)."""
+
+    def __init__(self, scene, device, rank, world_size, axis=None, margin=3.0, comm_on_cpu=False, capacity=None):
         import directx_renderer_kurth_amd as mi
-        self.rank, self.world_size, self.scene = rank, world_size, scene
+        self.rank, self.world_size, self.scene, self.comm_on_cpu = rank, world_size, scene, comm_on_cpu
         self.dev = torch.device("cuda", device)
         self.world = scene.instantiate(mi.World(device=device))
         n = scene.num_bodies
-        x0 = np.array([b[0][axis] for b in scene.bodies], np.float64)
-        self.exchanger = HaloExchanger(rank, world_size, quantile_cuts(x0, world_size), axis=axis, margin=margin, device=self.dev, comm_on_cpu=comm_on_cpu)
-        self.pose = torch.zeros((n, 8), dtype=torch.float32, device=self.dev)
-        self.vel = torch.zeros((n, 8), dtype=torch.float32, device=self.dev)
-        self.mask = torch.zeros(n, dtype=torch.uint8, device=self.dev)
-        self.world.state_to_device_buffers(self.pose.data_ptr(), self.vel.data_ptr())
-        self.code = self.exchanger.initial_code(self.pose)
-        self._push()
+        x0 = np.array([b[0] for b in scene.bodies], np.float64)
+        self.axis = max_variance_axis(x0) if axis is None else axis
+        cuts = quantile_cuts(x0[:, self.axis], world_size)
+        lo = cuts[rank - 1] if rank > 0 else -float("inf")
+        hi = cuts[rank] if rank < world_size - 1 else float("inf")
+        self.left = rank - 1 if rank > 0 else None
+        self.right = rank + 1 if rank < world_size - 1 else None
+        self.world.slab_configure(rank, world_size, self.axis, lo, hi, margin)
+        self.capacity = int(capacity or max(4096, n // max(2, world_size)))
+        nbytes = self.world.slab_message_bytes(self.capacity)
+        self.stream = torch.cuda.ExternalStream(self.world.device_pointers()[2], device=self.dev)  # the world's stream: torch's comm work is enqueued on it
+        with torch.cuda.stream(self.stream):
+            self.out = {nb: torch.zeros(nbytes, dtype=torch.uint8, device=self.dev) for nb in (self.left, self.right) if nb is not None}
+            self.inc = {nb: torch.zeros(nbytes, dtype=torch.uint8, device=self.dev) for nb in (self.left, self.right) if nb is not None}
+        self.bytes_sent = 0
+        self.host_syncs = 0      # synchronisations the exchange itself adds (0 on the RCCL path)
 
-    def _push(self):
-        self.mask.copy_((self.code != INACTIVE).to(torch.uint8))
-        torch.cuda.current_stream(self.dev).synchronize()
-        self.world.state_from_device_buffers(self.pose.data_ptr(), self.vel.data_ptr(), self.mask.data_ptr())
+    def _ptr(self, table, nb):
+        return table[nb].data_ptr() if nb is not None else 0
+
+    def exchange(self):
+        w = self.world
+        with torch.cuda.stream(self.stream):
+            w.slab_pack(self._ptr(self.out, self.left), self._ptr(self.out, self.right), self.capacity)
+            if self.comm_on_cpu:
+                host_out = {nb: t.cpu() for nb, t in self.out.items()}       # (synchronises: rehearsal path only)
+                host_in = {nb: torch.zeros_like(t) for nb, t in host_out.items()}
+                self.host_syncs += 1
+                ops = []
+                for nb in host_out:
+                    ops.append(dist.P2POp(dist.isend, host_out[nb], nb)); ops.append(dist.P2POp(dist.irecv, host_in[nb], nb))
+                for r in (dist.batch_isend_irecv(ops) if ops else []):
+                    r.wait()
+                for nb, t in host_in.items():
+                    self.inc[nb].copy_(t)
+            else:
+                ops = []
+                for nb in self.out:
+                    ops.append(dist.P2POp(dist.isend, self.out[nb], nb)); ops.append(dist.P2POp(dist.irecv, self.inc[nb], nb))
+                for r in (dist.batch_isend_irecv(ops) if ops else []):
+                    r.wait()                                                 # NCCL work: orders the stream, does not block the host
+            self.bytes_sent += sum(t.numel() for t in self.out.values())
+            w.slab_unpack(self._ptr(self.inc, self.left), self._ptr(self.inc, self.right), self.capacity)
 
     def step_internal(self, dt, iterations=30):
-        self.world.state_to_device_buffers(self.pose.data_ptr(), self.vel.data_ptr())  # synchronises the world's stream
-        self.exchanger.exchange(self.pose, self.vel, self.code)
-        self._push()
+        self.exchange()
         self.world.step_internal(dt, iterations)
+
+    def dropped(self):
+        """Bodies that did not fit this rank's last outgoing messages (must be 0: raise `capacity`)."""
+        return sum(int(t[4:8].cpu().view(torch.int32)[0]) for t in self.out.values())
 
     def synchronize(self):
         self.world.synchronize()
@@ -164,7 +211,8 @@ class SlabWorld:
         return self.world.stats()
 
     def gather_stats(self, acc):
-        """Sum the count-like statistics over ranks (stage times: max), in place on rank 0's accumulator."""
+        """Sum the count-like statistics over ranks (stage times: max), in place on rank 0's accumulator.  Pairs and contacts between
+        an owned body and a ghost exist on both sides of a cut and are counted twice (a few per cent of a slab)."""
         keys = sorted(acc.keys())
         t = torch.tensor([acc[k] for k in keys], dtype=torch.float64, device=self.dev)
         tmax = t.clone()
@@ -174,18 +222,17 @@ class SlabWorld:
             acc[k] = float(tmax[i]) if (k.startswith("ms") or k in ("numColors", "avgColors", "avgSteps", "numRigidBodies", "numColliders", "numInternalSteps", "numGraphBuilds", "coloringRounds")) else float(t[i])
 
     def owned_mask(self):
-        return (self.code == OWNED).cpu().numpy()
+        return self.world.slab_codes() == OWNED
 
     def transforms(self, which=1):
         """Global transforms assembled from every rank's owned bodies (collective)."""
-        t = torch.as_tensor(self.world.transforms(which), device=self.dev)
-        own = (self.code == OWNED).to(torch.float32)[:, None]
-        t = t * own
+        own = torch.as_tensor(self.owned_mask().astype(np.float32), device=self.dev)[:, None]
+        t = torch.as_tensor(self.world.transforms(which), device=self.dev) * own
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t.cpu().numpy()
 
     def velocities(self):
-        v = torch.as_tensor(self.world.velocities(), device=self.dev)
-        v = v * (self.code == OWNED).to(torch.float32)[:, None]
+        own = torch.as_tensor(self.owned_mask().astype(np.float32), device=self.dev)[:, None]
+        v = torch.as_tensor(self.world.velocities(), device=self.dev) * own
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         return v.cpu().numpy()
