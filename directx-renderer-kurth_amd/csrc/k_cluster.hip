@@ -24,6 +24,7 @@
 // mi_debug_read_schedule reports and the CPU oracle follows — with bit-identical arithmetic to the launch-per-colour sweep.
 #include "world.h"
 #include "solver_rows.h"
+#include "joint_solve.h"
 
 void prim_sort_pairs_u32(World& w, const u32* kin, u32* kout, const u32* vin, u32* vout, u32 n, u32 bits);
 void prim_exclusive_scan_u32(World& w, const u32* in, u32* out, u32 n);
@@ -123,9 +124,10 @@ MI_DEV u32 clBid(u32 slot, u32 count, u32 round, u32 i) { return (((4u - count) 
 #define CL_SUBCOUNTERS 8u // a task's append cursor is split in 8 (by workgroup) so that ~650 returning atomics do not queue on one address
 
 // Everything the assignment accumulates into, cleared in one launch.
-__global__ void __launch_bounds__(256) k_cl_clear(u32 nb1, u32* __restrict__ wsum, u32* __restrict__ phaseMask, u32* __restrict__ taskCount, u32* __restrict__ counters)
+__global__ void __launch_bounds__(256) k_cl_clear(u32 nb1, u32* __restrict__ wsum, u32* __restrict__ phaseMask, u32* __restrict__ taskCount, u32* __restrict__ jointCount, u32* __restrict__ counters)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < CL_MAX_TASKS) jointCount[i] = 0;
 	if (i < CL_MAX_PARTS * nb1) wsum[i] = 0;
 	if (i < nb1) phaseMask[i] = 0;
 	if (i < CL_MAX_PHASES * CL_MAX_TASKS * CL_SUBCOUNTERS) taskCount[i] = 0;
@@ -135,25 +137,52 @@ __global__ void __launch_bounds__(256) k_cl_clear(u32 nb1, u32* __restrict__ wsu
 
 MI_DEV u32 clWeight(u32 count) { return CL_WEIGHT_MANIFOLD + (count - 1u) * CL_WEIGHT_EXTRA; }
 
-__global__ void __launch_bounds__(256) k_cl_weights0(const u32* __restrict__ counters, u32 nb, const uint4* __restrict__ actIds, const u32* __restrict__ rank0,
+// rep: island representative per body (bodies connected by joints share one; the body itself otherwise; the dummy maps to itself).
+// In phase 0 a body counts where its representative is on the curve, so that an island is never cut.
+#define CL_WEIGHT_JOINT (6u * CL_WEIGHT_MANIFOLD) // a joint's solve costs several contact rows: at most ~160 joints per task
+__global__ void __launch_bounds__(256) k_cl_weights0(const u32* __restrict__ counters, u32 nb, const uint4* __restrict__ actIds, const u32* __restrict__ rank0, const u32* __restrict__ rep,
 	u32* __restrict__ wsum, u32* __restrict__ taskKey)
 {
 	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= counters[CTR_NUM_ACTIVE]) return;
 	uint4 ids = actIds[j];
-	u32 ra = rank0[ids.x], rb = rank0[ids.y]; // the dummy's rank is 0xFFFFFFFF
+	u32 ra = rank0[rep ? rep[ids.x] : ids.x], rb = rank0[rep ? rep[ids.y] : ids.y]; // the dummy's rank is 0xFFFFFFFF
 	atomicAdd(&wsum[min(ra, rb)], clWeight(ids.z));
 	taskKey[j] = CL_UNASSIGNED;
+}
+__global__ void __launch_bounds__(256) k_cl_joint_weights(u32 numJoints, const uint4* __restrict__ table, const u32* __restrict__ rank0, const u32* __restrict__ rep, u32* __restrict__ wsum)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= numJoints) return;
+	atomicAdd(&wsum[rank0[rep[table[i].z]]], CL_WEIGHT_JOINT);
+}
+// After phase 0's scan: every joint goes to the task of its island.
+__global__ void __launch_bounds__(256) k_cl_joint_assign(u32 numJoints, u32 taskWeight, const uint4* __restrict__ table, const u32* __restrict__ rank0, const u32* __restrict__ rep, const u32* __restrict__ cum,
+	u32* __restrict__ jointTask, u32* __restrict__ jointPos, u32* __restrict__ jointCount, u32* __restrict__ phaseMask, u32* __restrict__ status)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= numJoints) return;
+	uint4 e = table[i];
+	u32 t = cum[rank0[rep[e.z]]] / taskWeight;
+	if (t >= CL_MAX_TASKS) { atomicOr(status, 1u); t = CL_MAX_TASKS - 1u; }
+	jointTask[i] = t;
+	jointPos[i] = atomicAdd(&jointCount[t], 1u);
+	atomicOr(&phaseMask[e.z], 1u); atomicOr(&phaseMask[e.w], 1u);
+}
+__global__ void __launch_bounds__(256) k_cl_joint_scatter(u32 numJoints, const u32* __restrict__ jointTask, const u32* __restrict__ jointPos, const u32* __restrict__ jointStart, u32* __restrict__ jointList)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < numJoints) jointList[jointStart[jointTask[i]] + jointPos[i]] = i;
 }
 
 // Phase p: assign what is interior; what is left adds its weight to the next phase's curve, or (last partition) goes to the rest task.
 __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 phase, u32 numParts, u32 taskWeight, const uint4* __restrict__ actIds,
 	const u32* __restrict__ rank, const u32* __restrict__ cum, const u32* __restrict__ rankNext, u32* __restrict__ wsumNext,
-	u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask, u32* __restrict__ status)
+	u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask, u32* __restrict__ status, const u32* __restrict__ rep)
 {
 	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
 	const u32 entering = phase ? counters[CTR_CL_REMAIN + phase] : counters[CTR_NUM_ACTIVE];
-	const bool dumpAll = entering <= CL_REST_CAP; // few enough left: one task takes them all, later partitions stay empty
+	const bool dumpAll = entering <= CL_REST_CAP && !rep; // few enough left: one task takes them all, later partitions stay empty (with joints, phase 0 keeps the contacts of an island next to its joints)
 	bool pending = j < counters[CTR_NUM_ACTIVE] && taskKey[j] == CL_UNASSIGNED;
 	u32 key = CL_UNASSIGNED;
 	uint4 ids = make_uint4(0, 0, 0, 0);
@@ -165,7 +194,7 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 		if (dumpAll) key = CL_MAX_PARTS * CL_MAX_TASKS;
 		else
 		{
-			u32 ta = da ? cum[rank[ids.x]] / taskWeight : 0u, tb = db ? cum[rank[ids.y]] / taskWeight : 0u;
+			u32 ta = da ? cum[rank[rep ? rep[ids.x] : ids.x]] / taskWeight : 0u, tb = db ? cum[rank[rep ? rep[ids.y] : ids.y]] / taskWeight : 0u; // rep: phase 0 with joints only
 			if (!da) ta = tb;
 			if (!db) tb = ta;
 			if (ta == tb)
@@ -197,7 +226,7 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 }
 
 // One workgroup: exclusive scan of the per-task counts -> first slot of every task; tasks per phase; end of schedule.
-__global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters, u32 numParts, const u32* __restrict__ taskCount, u32* __restrict__ taskStart)
+__global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters, u32 numParts, const u32* __restrict__ taskCount, u32* __restrict__ taskStart, const u32* __restrict__ jointCount, u32* __restrict__ jointStart)
 {
 	__shared__ u32 part[1024];
 	__shared__ u32 lastTask[CL_MAX_PHASES];
@@ -220,10 +249,21 @@ __global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters,
 	}
 	if (t == 1023u) taskStart[total] = run;
 	__syncthreads();
+	// joints per phase-0 task (CL_MAX_TASKS <= 1024 entries: one per lane); a task may hold joints and no manifold
+	{
+		u32 jc = (jointCount && t < CL_MAX_TASKS) ? jointCount[t] : 0u;
+		part[t] = jc;
+		__syncthreads();
+		for (u32 o = 1; o < 1024u; o <<= 1) { u32 v = (t >= o) ? part[t - o] : 0u; __syncthreads(); part[t] += v; __syncthreads(); }
+		if (jointStart && t < CL_MAX_TASKS) { jointStart[t] = part[t] - jc; if (t == CL_MAX_TASKS - 1u) jointStart[CL_MAX_TASKS] = part[t]; }
+		if (jc) atomicMax(&lastTask[0], t + 1u);
+		__syncthreads();
+	}
+	const u32 totalManifolds = taskStart[total];
 	if (t < CL_MAX_PHASES) counters[CTR_CL_NUM_TASKS + t] = lastTask[t];
 	if (t == 0)
 	{
-		counters[CTR_NUM_MANIFOLDS] = part[1023];
+		counters[CTR_NUM_MANIFOLDS] = totalManifolds;
 		counters[CTR_NUM_COLORS] = 0; // k_cl_color: atomicMax of the local colour counts
 		for (int k = 0; k < 3; ++k) { counters[CTR_CL_BBOX + k] = 0xFFFFFFFFu; counters[CTR_CL_BBOX + 3 + k] = 0u; } // consumed by k_cl_keys: ready for the next step
 	}
@@ -253,7 +293,8 @@ struct ClTask
 static_assert(sizeof(ClTask) == 320, "task header");
 
 __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u32 nb, const u32* __restrict__ taskStart, const u32* __restrict__ pre, const uint4* __restrict__ actIds,
-	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ bodyUsers, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ mExtra, u32* __restrict__ mRank, u32* __restrict__ sharedSlot)
+	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ bodyUsers, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ mExtra, u32* __restrict__ mRank, u32* __restrict__ sharedSlot,
+	const u32* __restrict__ jointStart, const u32* __restrict__ jointList, const uint4* __restrict__ jointTable, uint2* __restrict__ taskJoints, u32* __restrict__ jointClassStart)
 {
 	extern __shared__ u32 clds[];
 	u32* hKey = clds;                                   // [CL_HASH_SIZE] global id + 1, 0 = empty
@@ -266,6 +307,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 	u32* mCnt = mPos + CL_TASK_MAX_MANIFOLDS;           // [..] contact count by final position, then its exclusive scan of (count - 1)
 	u32* mSlot = mCnt + CL_TASK_MAX_MANIFOLDS;          // [..] narrowphase slot | contacts << 28 (the colouring rounds' priorities hash it)
 	u32* hist = mSlot + CL_TASK_MAX_MANIFOLDS;          // [264] per key, then cursors
+	u32* jHist = hist + 264;                            // [CL_MAX_JOINT_CLASSES + 1] joints per (type, colour) class, then cursors
 	__shared__ u32 sNumShared, sNumPrivate, sLeftA, sLeftB, sMaxColor, sScan[16], sSharedBase;
 	const u32 tid = threadIdx.x;
 	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
@@ -274,11 +316,15 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 	{
 		u32 first = taskStart[key * CL_SUBCOUNTERS], n = taskStart[(key + 1u) * CL_SUBCOUNTERS] - first;
 		ClTask* T = tasks + key;
-		if (!n) { if (tid == 0) { T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } continue; }
-		if (n > CL_TASK_MAX_MANIFOLDS) { if (tid == 0) { atomicOr(&counters[CTR_CL_STATUS], 2u); T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } continue; }
+		// joints of the task (phase 0 only: an island lives in one phase-0 task)
+		const u32 jFirst = (jointStart && key < CL_MAX_TASKS) ? jointStart[key] : 0u, nj = (jointStart && key < CL_MAX_TASKS) ? jointStart[key + 1u] - jFirst : 0u;
+		if (jointStart && key < CL_MAX_TASKS && tid <= CL_MAX_JOINT_CLASSES) jointClassStart[(size_t)key * (CL_MAX_JOINT_CLASSES + 2u) + tid] = 0u; // (no joints: all classes empty)
+		if (jointStart && key < CL_MAX_TASKS && tid == 0) jointClassStart[(size_t)key * (CL_MAX_JOINT_CLASSES + 2u) + CL_MAX_JOINT_CLASSES + 1u] = jFirst;
+		if (!n && !nj) { if (tid == 0) { T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } continue; }
+		if (n > CL_TASK_MAX_MANIFOLDS || nj > CL_TASK_MAX_JOINTS) { if (tid == 0) { atomicOr(&counters[CTR_CL_STATUS], 2u); T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } continue; }
 		u32 phase = key / CL_MAX_TASKS;
 		for (u32 h = tid; h < CL_HASH_SIZE; h += CL_LANES) hKey[h] = 0;
-		for (u32 h = tid; h < 264u; h += CL_LANES) hist[h] = 0;
+		for (u32 h = tid; h < 264u + CL_MAX_JOINT_CLASSES + 1u; h += CL_LANES) hist[h] = 0;
 		if (tid == 0) { sNumShared = 0; sNumPrivate = 0; sMaxColor = 0; }
 		__syncthreads();
 		// 1. distinct dynamic bodies
@@ -288,6 +334,22 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			for (u32 e = 0; e < 2; ++e)
 			{
 				u32 g = e ? ids.y : ids.x;
+				if (g >= nb) continue;
+				u32 h = clHash(g) & (CL_HASH_SIZE - 1u);
+				for (;;)
+				{
+					u32 old = atomicCAS(&hKey[h], 0u, g + 1u);
+					if (old == 0u || old == g + 1u) break;
+					h = (h + 1u) & (CL_HASH_SIZE - 1u);
+				}
+			}
+		}
+		for (u32 i = tid; i < nj; i += CL_LANES) // the joints' bodies: a limb in the air has joints and no contact
+		{
+			uint4 e4 = jointTable[jointList[jFirst + i]];
+			for (u32 e = 0; e < 2; ++e)
+			{
+				u32 g = e ? e4.w : e4.z;
 				if (g >= nb) continue;
 				u32 h = clHash(g) & (CL_HASH_SIZE - 1u);
 				for (;;)
@@ -345,6 +407,37 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			mSlot[i] = (ids.w & 0x0FFFFFFFu) | (ids.z << 28);
 		}
 		__syncthreads();
+		// 2b. the joints: local ids of their bodies, ordered by (type, colour) class (counting sort: class sizes, offsets, cursors)
+		if (nj)
+		{
+			for (u32 i = tid; i < nj; i += CL_LANES) atomicAdd(&jHist[min(jointTable[jointList[jFirst + i]].x >> 8, CL_MAX_JOINT_CLASSES - 1u)], 1u);
+			__syncthreads();
+			if (tid == 0)
+			{
+				u32 run = 0;
+				for (u32 c = 0; c < CL_MAX_JOINT_CLASSES; ++c) { u32 v = jHist[c]; jHist[c] = run; jointClassStart[(size_t)key * (CL_MAX_JOINT_CLASSES + 2u) + c] = run; run += v; }
+				jointClassStart[(size_t)key * (CL_MAX_JOINT_CLASSES + 2u) + CL_MAX_JOINT_CLASSES] = run;
+			}
+			__syncthreads();
+			for (u32 i = tid; i < nj; i += CL_LANES)
+			{
+				u32 ji = jointList[jFirst + i];
+				uint4 e4 = jointTable[ji];
+				u32 loc[2];
+				for (u32 e = 0; e < 2; ++e)
+				{
+					u32 g = e ? e4.w : e4.z;
+					loc[e] = CL_LOCAL_STATIC;
+					if (g >= nb) continue;
+					u32 h = clHash(g) & (CL_HASH_SIZE - 1u);
+					while (hKey[h] != g + 1u) h = (h + 1u) & (CL_HASH_SIZE - 1u);
+					loc[e] = hVal[h];
+				}
+				u32 p = atomicAdd(&jHist[min(e4.x >> 8, CL_MAX_JOINT_CLASSES - 1u)], 1u); // (order inside a class is free: its joints share no body)
+				taskJoints[jFirst + p] = make_uint2(ji, loc[0] | (loc[1] << 16));
+			}
+			__syncthreads();
+		}
 		// 3. colouring rounds.  A claim word holds {round, inverted bid}: a later round's bid beats any earlier one under atomicMax, so
 		// the claims need no clearing between rounds: two barriers per round (bid | decide).  The two sLeft counters alternate by round
 		// parity so that the next round's reset cannot overtake this round's readers.
@@ -486,7 +579,7 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 struct ClLocal // a task of this workgroup, in LDS
 {
-	u32 first, count, numBodies, numShared, numColors, serialStart, phase, key, sharedBase;
+	u32 first, count, numBodies, numShared, numColors, serialStart, phase, key, sharedBase, numJoints;
 	u32 bodyOff;   // float4 index of the task's bodies (2 float4 each)
 	u32 infoOff;   // u32 index (in float4 units * 4) of per-body {global id, turn info}
 	u32 metaOff;   // float4 index of the per-manifold meta (not for the register task): {la|lb<<16, key|extra<<10, -, -}, {n.xyz, friction}
@@ -519,6 +612,10 @@ struct ClArgs
 	const float4* rowPlanes; const float4* rowShared; float2* rowLambda;
 	float4* vel; u64* flow; u64* trace; // trace: developer timeline (mi_debug_flow_trace), normally null
 	size_t rowCap; u32 nb, flowBytes, epoch, itBegin, itEnd, ldsFloat4s;
+	// joints run by the sweep (null / 0 when the world has none or they keep their own launches): per phase-0 task the class offsets
+	// [CL_MAX_JOINT_CLASSES + 2] (last two: joint count, first entry), the class-sorted entries {table index, la | lb << 16}, the table
+	// {type | class << 8, index in the type's arrays, body a, body b}, the per-type update records, world inverse inertia
+	const u32* jointClassStart; const uint2* taskJoints; const uint4* jointTable; float* jointUpd[MI_JOINT_TYPES]; const float4* invIw; u32 numJointClasses;
 };
 
 // One manifold: both bodies from LDS, its rows (registers / LDS / global memory), both bodies back.
@@ -591,7 +688,8 @@ MI_DEV void clSolveReg(float4* lds, const ClArgs& A, u32 rdA, u32 wrA, u32 rdB, 
 	lds[wrB] = make_float4(vB.x, vB.y, vB.z, invMassB); lds[wrB + 1] = make_float4(wB.x, wB.y, wB.z, 0.f);
 }
 
-__global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
+// JOINTS: the instantiation for worlds whose joints run inside the sweep (its extra registers and code stay out of the other one).
+template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 {
 	extern __shared__ float4 lds[];
 	__shared__ ClLocal sTask[CL_MAX_PHASES];
@@ -616,10 +714,12 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 			if (t >= tasksInPhase) continue;
 			u32 key = p * CL_MAX_TASKS + t;
 			const ClTask* T = A.tasks + key;
-			if (!T->count) continue;
+			const u32 tj = (A.jointClassStart && p == 0u) ? A.jointClassStart[(size_t)key * (CL_MAX_JOINT_CLASSES + 2u) + CL_MAX_JOINT_CLASSES] : 0u; // joints of the task
+			if (!T->count && !tj) continue;
 			ClLocal& L = sTask[nT];
 			L.first = T->first; L.count = T->count; L.numBodies = T->numBodies; L.numShared = T->numShared; L.numColors = T->numColors; L.serialStart = T->serialStart;
-			L.phase = p; L.key = key; L.sharedBase = T->sharedBase;
+			L.phase = p; L.key = key; L.sharedBase = T->sharedBase; L.numJoints = tj;
+			if (tj > CLS_LANES) bad = true; // one lane per joint
 			for (u32 c = 0; c <= CL_SERIAL_COLOR + 1u; ++c) L.colorStart[c] = T->colorStart[c];
 			L.bodyOff = used; used += 2u * L.numBodies;
 			L.infoOff = used * 4u; used += (3u * L.numBodies + 3u) / 4u;
@@ -717,6 +817,20 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 	const u32 rdA1 = (regAB1 & 0xFFFFu) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB1 & 0xFFFFu), wrA1 = (regAB1 & 0xFFFFu) == CL_LOCAL_STATIC ? sinkRec : rdA1;
 	const u32 rdB1 = (regAB1 >> 16) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB1 >> 16), wrB1 = (regAB1 >> 16) == CL_LOCAL_STATIC ? sinkRec : rdB1;
 	const u32 rowOff0 = __builtin_amdgcn_readfirstlane(sTask[0].rowOff), rowCap0 = __builtin_amdgcn_readfirstlane(sTask[0].rowCap), first0 = __builtin_amdgcn_readfirstlane(sTask[0].first);
+	// this lane's joint (first task only, phase 0): class, update record, the two bodies as LDS addresses and as global ids (inverse inertia)
+	u32 jClass = 0xFFFFFFFFu, jType = 0, jA = 0, jB = 0, jRdA = zeroRec, jWrA = sinkRec, jRdB = zeroRec, jWrB = sinkRec; float* jRec = nullptr;
+	const u32 numJoints0 = (JOINTS && sTask[0].phase == 0u) ? sTask[0].numJoints : 0u;
+	if (JOINTS && tid < numJoints0)
+	{
+		const u32* cs = A.jointClassStart + (size_t)sTask[0].key * (CL_MAX_JOINT_CLASSES + 2u);
+		uint2 e = A.taskJoints[cs[CL_MAX_JOINT_CLASSES + 1u] + tid];
+		uint4 t4 = A.jointTable[e.x];
+		jType = t4.x & 0xFFu; jClass = t4.x >> 8; jA = t4.z; jB = t4.w;
+		jRec = A.jointUpd[jType] + (size_t)t4.y * jointUpdateFloats(jType);
+		u32 la = e.y & 0xFFFFu, lb = e.y >> 16;
+		if (la != CL_LOCAL_STATIC) { jRdA = bodyOff0 + 2u * la; jWrA = jRdA; }
+		if (lb != CL_LOCAL_STATIC) { jRdB = bodyOff0 + 2u * lb; jWrB = jRdB; }
+	}
 	__syncthreads();
 	// developer timeline: 16 rows of 32 stamps per workgroup: row 3 k = "task k acquired its shared bodies" in iteration (column), row
 	// 3 k + 1 = "task k's colours done"; rows 5-6: core-clock stamp after every colour of iteration 10 of the first task, rows 7-8: the
@@ -798,6 +912,25 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 			if (sAbort) { aborted = true; break; }
 			if (k == 0 && it > A.itBegin) lastWait = (u32)(wall_clock64() - lastPublish);
 			if (trace && tid == 0 && it - A.itBegin < 32u && k < 5u) trace[(3 * k) * 32 + (it - A.itBegin)] = wall_clock64();
+			// joints first (constraints.cpp:3748-3772: all joint types, then the contacts): one (type, colour) class per step
+			if (JOINTS && k == 0 && numJoints0)
+			{
+				const u32* cs = A.jointClassStart + (size_t)L.key * (CL_MAX_JOINT_CLASSES + 2u);
+				for (u32 c = 0; c < A.numJointClasses; ++c)
+				{
+					if (cs[c + 1u] == cs[c]) continue; // (uniform: the class has no joint in this task)
+					if (jClass == c)
+					{
+						Vel v; float4 a0 = lds[jRdA], a1 = lds[jRdA + 1], b0 = lds[jRdB], b1 = lds[jRdB + 1];
+						v.vA = v3f4(a0); v.wA = v3f4(a1); v.vB = v3f4(b0); v.wB = v3f4(b1); v.invMassA = a0.w; v.invMassB = b0.w;
+						M3 IA = ldInvI(A.invIw, jA), IB = ldInvI(A.invIw, jB);
+						jointSolve(jType, jRec, v, IA, IB);
+						lds[jWrA] = make_float4(v.vA.x, v.vA.y, v.vA.z, v.invMassA); lds[jWrA + 1] = make_float4(v.wA.x, v.wA.y, v.wA.z, 0.f);
+						lds[jWrB] = make_float4(v.vB.x, v.vB.y, v.vB.z, v.invMassB); lds[jWrB + 1] = make_float4(v.wB.x, v.wB.y, v.wB.z, 0.f);
+					}
+					__syncthreads();
+				}
+			}
 			// colours
 			if (L.inRegs)
 			{
@@ -913,8 +1046,10 @@ __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 // ---------------------------------------------------------------------------------------------------------------
 static size_t clColorLdsBytes()
 {
-	return sizeof(u32) * (2 * CL_HASH_SIZE + (CL_TASK_MAX_BODIES + 1) + 5 * CL_TASK_MAX_MANIFOLDS + 264) + sizeof(u64) * (CL_TASK_MAX_BODIES + 1);
+	return sizeof(u32) * (2 * CL_HASH_SIZE + (CL_TASK_MAX_BODIES + 1) + 5 * CL_TASK_MAX_MANIFOLDS + 264 + CL_MAX_JOINT_CLASSES + 1) + sizeof(u64) * (CL_TASK_MAX_BODIES + 1);
 }
+
+bool cluster_solves_joints(const World& w) { return w.clJointsInCluster && w.useClusterJoints; }
 
 bool cluster_available(World& w)
 {
@@ -923,10 +1058,11 @@ bool cluster_available(World& w)
 	MI_CHECK(hipDeviceGetAttribute(&maxLds, hipDeviceAttributeMaxSharedMemoryPerBlock, w.device));
 	MI_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, w.device));
 	hipFuncAttributes fa = {};
-	MI_CHECK(hipFuncGetAttributes(&fa, (const void*)k_cl_solve));
+	MI_CHECK(hipFuncGetAttributes(&fa, (const void*)k_cl_solve<true>));
 	size_t dyn = (maxLds > 0 ? (size_t)maxLds : 65536) - fa.sharedSizeBytes - 256;
 	dyn &= ~(size_t)15;
-	if (hipFuncSetAttribute((const void*)k_cl_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess
+	if (hipFuncSetAttribute((const void*)k_cl_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess
+		|| hipFuncSetAttribute((const void*)k_cl_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess
 		|| hipFuncSetAttribute((const void*)k_cl_color, hipFuncAttributeMaxDynamicSharedMemorySize, (int)clColorLdsBytes()) != hipSuccess)
 	{
 		(void)hipGetLastError();
@@ -974,19 +1110,31 @@ void launch_cluster_build(World& w, u32 numPairs)
 	// tasks
 	const u32 parts = w.clusterParts;
 	u32 clearItems = std::max<u32>((u32)(CL_MAX_PARTS * nb1), totalKeys * CL_SUBCOUNTERS);
-	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.dCounters.p);
-	hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, w.clWsum.p, w.clTaskKey.p);
+	const bool withJoints = cluster_solves_joints(w);
+	const u32* rep = withJoints ? w.clRep.p : nullptr;
+	const u32 nj = withJoints ? w.clNumJoints : 0u;
+	w.clJointCount.ensure(CL_MAX_TASKS, w.stream); w.clJointStart.ensure(CL_MAX_TASKS + 1, w.stream);
+	w.clJointTask.ensure(std::max(nj, 1u), w.stream); w.clJointPos.ensure(std::max(nj, 1u), w.stream); w.clJointList.ensure(std::max(nj, 1u), w.stream); w.clTaskJoints.ensure(std::max(nj, 1u), w.stream);
+	w.clJointClassStart.ensure((size_t)CL_MAX_TASKS * (CL_MAX_JOINT_CLASSES + 2u), w.stream);
+	if (w.lastError) return;
+	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.clJointCount.p, w.dCounters.p);
+	hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, rep, w.clWsum.p, w.clTaskKey.p);
+	if (nj) hipLaunchKernelGGL(k_cl_joint_weights, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clRank.p, rep, w.clWsum.p);
 	for (u32 p = 0; p < parts; ++p)
 	{
 		u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
 		prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
 		hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, w.clusterTaskWeight, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
-			w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
+			w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, p == 0 ? rep : nullptr);
+		if (p == 0 && nj) // (cum still holds phase 0's scan)
+			hipLaunchKernelGGL(k_cl_joint_assign, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clusterTaskWeight, w.clJointTable.p, w.clRank.p, rep, w.clCum.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
 	}
-	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, parts, w.clTaskCount.p, w.clTaskStart.p);
+	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, parts, w.clTaskCount.p, w.clTaskStart.p, nj ? w.clJointCount.p : (u32*)nullptr, nj ? w.clJointStart.p : (u32*)nullptr);
+	if (nj) hipLaunchKernelGGL(k_cl_joint_scatter, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTask.p, w.clJointPos.p, w.clJointStart.p, w.clJointList.p);
 	hipLaunchKernelGGL(k_cl_scatter, mgrid, block, 0, w.stream, w.dCounters.p, w.clTaskKey.p, w.clTaskPos.p, w.clTaskStart.p, w.clPre.p);
 	hipLaunchKernelGGL(k_cl_color, dim3(w.clusterBlocks), dim3(CL_LANES), clColorLdsBytes(), w.stream, w.dCounters.p, nb, w.clTaskStart.p, w.clPre.p, w.actIds.p,
-		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.clBodyUsers.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clExtra.p, w.clRankInfo.p, w.clSharedSlot.p);
+		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.clBodyUsers.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clExtra.p, w.clRankInfo.p, w.clSharedSlot.p,
+		nj ? w.clJointStart.p : (const u32*)nullptr, w.clJointList.p, w.clJointTable.p, w.clTaskJoints.p, w.clJointClassStart.p);
 }
 
 // Iterations [itBegin, itEnd) of the contact sweep in one launch.
@@ -1013,5 +1161,9 @@ void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd)
 	A.rowPlanes = w.rowPlanes.p; A.rowShared = w.rowShared.p; A.rowLambda = w.rowLambda.p; A.vel = w.vel.p; A.flow = w.flow.p; A.trace = w.flowTrace.p;
 	A.rowCap = w.rowCap; A.nb = w.nb; A.flowBytes = (u32)(words * sizeof(u64)); A.epoch = w.flowEpoch << 16; A.itBegin = itBegin; A.itEnd = itEnd;
 	A.ldsFloat4s = w.clusterLdsBytes / 16u;
-	hipLaunchKernelGGL(k_cl_solve, dim3(w.clusterBlocks), dim3(CLS_LANES), w.clusterLdsBytes, w.stream, A);
+	const bool withJoints = cluster_solves_joints(w);
+	A.jointClassStart = withJoints ? w.clJointClassStart.p : nullptr; A.taskJoints = w.clTaskJoints.p; A.jointTable = w.clJointTable.p; A.invIw = w.invIw.p; A.numJointClasses = withJoints ? w.clNumJointClasses : 0u;
+	for (u32 t = 0; t < MI_JOINT_TYPES; ++t) A.jointUpd[t] = w.joints[t].dUpdate.p;
+	if (withJoints) hipLaunchKernelGGL(k_cl_solve<true>, dim3(w.clusterBlocks), dim3(CLS_LANES), w.clusterLdsBytes, w.stream, A);
+	else hipLaunchKernelGGL(k_cl_solve<false>, dim3(w.clusterBlocks), dim3(CLS_LANES), w.clusterLdsBytes, w.stream, A);
 }

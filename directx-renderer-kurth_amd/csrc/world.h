@@ -101,6 +101,8 @@ enum
 #define CL_MAX_PHASES (CL_MAX_PARTS + 1u)
 #define CL_MAX_TASKS 512u
 #define CL_BODY_STRIDE 4096u
+#define CL_MAX_JOINT_CLASSES 64u   // (type, colour) classes of joints the cluster sweep can run
+#define CL_TASK_MAX_JOINTS 512u    // joints per task (one lane each)
 #define MI_NUM_SCHEDULE_KEYS ((MI_MAX_COLORS + 1) * 4)
 
 struct World
@@ -185,6 +187,11 @@ struct World
 	u32 clusterLdsBytes = 0, clusterBlocks = 0, clusterCooldown = 0;
 	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clExtra, clTaskCount, clTaskStart, clBodyList, clBodyUsers, clRankInfo, clSharedSlot;
 	DevBuf<uint8_t> clTasks;
+	// joints inside the cluster sweep: island representative per body (jointed bodies must share a task), the joints of all types in
+	// (type, colour) order {type | class << 8, index in the type's colour-sorted arrays, body a, body b}, and the per-step lists
+	DevBuf<u32> clRep, clJointTask, clJointPos, clJointCount, clJointStart, clJointList; DevBuf<uint4> clJointTable; DevBuf<uint2> clTaskJoints; DevBuf<u32> clJointClassStart;
+	bool useClusterJoints = true;         // MI_CLUSTER_NO_JOINTS=1: joints keep their per-colour launches (one cluster launch per iteration then)
+	u32 clNumJoints = 0, clNumJointClasses = 0; bool clJointsInCluster = false; // false: more (type, colour) classes than the kernel's table: joints keep their launches
 	DevBuf<u64> flowTrace;                // developer timeline (mi_debug_flow_trace): 32 x u64 per slot, allocated on request only
 	u32 flowEpoch = 0, flowMaxBlocks[2] = { 0, 0 };
 	bool useFlow = true;                  // MI_PHYSICS_NO_FLOW=1: launch-per-colour sweep only
@@ -270,6 +277,7 @@ bool cluster_available(World& w);                          // sets up the cluste
 void launch_active_list(World& w, u32 numPairs);           // manifolds with contacts -> actIds (no colours)
 void launch_cluster_build(World& w, u32 numPairs);         // body order, tasks, local colouring, final slot order (k_cluster.hip)
 void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd);
+bool cluster_solves_joints(const World& w);                // the cluster sweep of this step runs the joints too (one launch for all iterations)
 void launch_flow_regions(World& w, u32 numManifolds);       // region-major slot order for the XCD-local dataflow sweep
 u32 flow_num_regions(const World& w);
 void flow_choose_regions(World& w);

@@ -49,7 +49,8 @@ World::World(int dev) : device(dev)
 	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
 	useGraph = getenv("MI_PHYSICS_NO_GRAPH") == nullptr; // rocprofv3's kernel trace needs plain launches
 	validate = getenv("MI_PHYSICS_VALIDATE") != nullptr;
-	useCluster = getenv("MI_PHYSICS_NO_CLUSTER") == nullptr; // LDS cluster contact sweep (one launch) vs global colouring + one launch per colour
+	useCluster = getenv("MI_PHYSICS_NO_CLUSTER") == nullptr;
+	useClusterJoints = getenv("MI_CLUSTER_NO_JOINTS") == nullptr; // LDS cluster contact sweep (one launch) vs global colouring + one launch per colour
 	useFusedColoring = false;                                // the launch sweep colours with one launch per round (no grid barrier)
 	useWarmColoring = getenv("MI_PHYSICS_NO_WARM_COLORING") == nullptr;
 	if (const char* e = getenv("MI_COLOR_FULL_INTERVAL")) fullColoringInterval = (u32)atoi(e);
@@ -413,6 +414,39 @@ void World::uploadJoints()
 		MI_CHECK(hipMemcpyAsync(js.dPairs.p, hpr.data(), sizeof(uint2) * m, hipMemcpyHostToDevice, stream));
 		MI_CHECK(hipStreamSynchronize(stream));
 	}
+	// Joints inside the cluster sweep: bodies connected by joints form an island that must live in ONE task (a joint is solved out of
+	// the task's LDS like a contact, and joints come before contacts in every iteration: constraints.cpp:3748-3772), so every body
+	// gets its island's representative (lowest body index), and the joints are listed once in (type, colour) order.
+	{
+		const u32 n = (u32)bodies.size();
+		std::vector<u32> rep(n + 1);
+		for (u32 i = 0; i <= n; ++i) rep[i] = i;
+		auto find = [&](u32 x) { while (rep[x] != x) { rep[x] = rep[rep[x]]; x = rep[x]; } return x; };
+		std::vector<uint4> table;
+		u32 numClasses = 0;
+		for (u32 t = 0; t < MI_JOINT_TYPES; ++t)
+		{
+			JointSet& js = joints[t];
+			for (size_t c = 0; c + 1 < js.colorStart.size(); ++c)
+			{
+				for (u32 sidx = js.colorStart[c]; sidx < js.colorStart[c + 1]; ++sidx)
+				{
+					u32 i = js.order[sidx], a = js.a[i], b = js.b[i];
+					table.push_back(make_uint4(t | (numClasses << 8), sidx, a, b));
+					u32 ra = find(a), rb = find(b);
+					if (ra != rb) { if (ra < rb) rep[rb] = ra; else rep[ra] = rb; }
+				}
+				if (js.colorStart[c + 1] > js.colorStart[c]) ++numClasses;
+			}
+		}
+		for (u32 i = 0; i < n; ++i) rep[i] = find(i);
+		clNumJoints = (u32)table.size(); clNumJointClasses = numClasses;
+		clJointsInCluster = clNumJoints > 0 && numClasses <= CL_MAX_JOINT_CLASSES;
+		clRep.ensure(n + 1, stream); clJointTable.ensure(std::max<size_t>(table.size(), 1), stream);
+		MI_CHECK(hipMemcpyAsync(clRep.p, rep.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, stream));
+		if (!table.empty()) MI_CHECK(hipMemcpyAsync(clJointTable.p, table.data(), sizeof(uint4) * table.size(), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipStreamSynchronize(stream));
+	}
 	jointsDirty = false; jointVersion++;
 }
 
@@ -692,7 +726,7 @@ int World::stepInternal(float dt, u32 iters)
 		pendingDt = dt; pendingIters = iters; flowPending = true; forceFullColoring = true;
 		u32 numJointKernels = 0;
 		for (auto& js : joints) numJointKernels += js.colorStart.empty() ? 0 : (u32)js.colorStart.size() - 1;
-		if (!numJointKernels) launch_cluster_solve(*this, 0, iters);
+		if (!numJointKernels || cluster_solves_joints(*this)) launch_cluster_solve(*this, 0, iters);
 		else for (u32 it = 0; it < iters; ++it) { launch_joint_solve_iteration(*this); launch_cluster_solve(*this, it, it + 1); } // joints before contacts in every iteration (constraints.cpp:3748-3772)
 	}
 	else
