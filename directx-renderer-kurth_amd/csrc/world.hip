@@ -442,6 +442,7 @@ void World::uploadJoints()
 		for (u32 i = 0; i < n; ++i) rep[i] = find(i);
 		clNumJoints = (u32)table.size(); clNumJointClasses = numClasses;
 		clJointsInCluster = clNumJoints > 0 && numClasses <= CL_MAX_JOINT_CLASSES;
+		if (getenv("MI_CLUSTER_DEBUG")) fprintf(stderr, "[mi_physics] joints: %u in %u (type, colour) classes -> %s\n", clNumJoints, numClasses, clJointsInCluster ? "inside the cluster sweep" : "own launches");
 		clRep.ensure(n + 1, stream); clJointTable.ensure(std::max<size_t>(table.size(), 1), stream);
 		MI_CHECK(hipMemcpyAsync(clRep.p, rep.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, stream));
 		if (!table.empty()) MI_CHECK(hipMemcpyAsync(clJointTable.p, table.data(), sizeof(uint4) * table.size(), hipMemcpyHostToDevice, stream));
