@@ -292,7 +292,7 @@ struct ClTask
 };
 static_assert(sizeof(ClTask) == 320, "task header");
 
-__global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u32 nb, const u32* __restrict__ taskStart, const u32* __restrict__ pre, const uint4* __restrict__ actIds,
+__global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u32 nb, const u32* __restrict__ taskStart, u32* __restrict__ pre, const uint4* __restrict__ actIds,
 	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ bodyUsers, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ mExtra, u32* __restrict__ mRank, u32* __restrict__ sharedSlot,
 	const u32* __restrict__ jointStart, const u32* __restrict__ jointList, const uint4* __restrict__ jointTable, uint2* __restrict__ taskJoints, u32* __restrict__ jointClassStart)
 {
@@ -388,10 +388,39 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			}
 		for (u32 l = tid; l <= numBodies; l += CL_LANES) { mask[l] = 0ull; claim[l] = 0xFFFFFFFFu; }
 		__syncthreads();
+		// 1b. The task's manifolds arrive in the order their append atomics landed.  The colouring below breaks bid ties by position, so
+		// the positions are made a function of the inputs first: bitonic sort by narrowphase slot (unique per manifold).  With that the
+		// whole schedule, and so every result, repeats from run to run (snapshot / restore continue bit-identically).  Stages that
+		// exchange inside 128 consecutive elements stay inside one wave and need no workgroup barrier.
+		{
+			u32 m = 128u; while (m < n) m <<= 1;
+			u32* sKey = mSlot; u32* sVal = mPos;
+			for (u32 i = tid; i < m; i += CL_LANES)
+			{
+				u32 pi = (i < n) ? pre[first + i] : 0u;
+				sKey[i] = (i < n) ? (actIds[pi].w & 0x0FFFFFFFu) : 0xFFFFFFFFu; sVal[i] = pi;
+			}
+			__syncthreads();
+			for (u32 k = 2u; k <= m; k <<= 1)
+				for (u32 j = k >> 1; j > 0u; j >>= 1)
+				{
+					if (tid < (m >> 1))
+					{
+						u32 a = 2u * j * (tid / j) + (tid % j), b = a + j;
+						bool up = (a & k) == 0u;
+						u32 ka = sKey[a], kb = sKey[b];
+						if ((ka > kb) == up) { u32 va = sVal[a], vb = sVal[b]; sKey[a] = kb; sKey[b] = ka; sVal[a] = vb; sVal[b] = va; }
+					}
+					if (j > 64u || (j == 1u && k >= 128u)) __syncthreads(); // the next stage (j / 2, or the next k's first) crosses the waves' 128-element blocks
+					else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				}
+			__syncthreads();
+			for (u32 i = tid; i < n; i += CL_LANES) pre[first + i] = sVal[i]; // (read again when the final order is written out)
+		}
 		// 2. local ids of every manifold
 		for (u32 i = tid; i < n; i += CL_LANES)
 		{
-			uint4 ids = actIds[pre[first + i]];
+			uint4 ids = actIds[mPos[i]];
 			u32 loc[2];
 			for (u32 e = 0; e < 2; ++e)
 			{
@@ -508,10 +537,16 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			atomicAdd(&counters[CTR_CL_PHASE_COUNT + phase], n);
 		}
 		__syncthreads();
-		// Positions inside a (colour, count) class follow the narrowphase slot order, so the schedule is a deterministic function of
-		// the inputs: rank of the manifold among its class = number of class members with a smaller slot ... that is quadratic; use
-		// an atomic cursor (order inside a class is free: its manifolds share no body) and keep determinism of RESULTS, not of the order.
-		for (u32 i = tid; i < n; i += CL_LANES) { u32 p = atomicAdd(&hist[mKey[i]], 1u); mPos[i] = p; mCnt[p] = (4u - (mKey[i] & 3u)); }
+		// Positions inside a (colour, count) class: an atomic cursor (order inside a class is free, its manifolds share no body: the
+		// RESULTS repeat from run to run, the memory order need not).
+		// The serial tail IS order-dependent: its positions follow the (sorted) index.
+		for (u32 i = tid; i < n; i += CL_LANES)
+		{
+			u32 k = mKey[i], p;
+			if ((k >> 2) < CL_SERIAL_COLOR) p = atomicAdd(&hist[k], 1u);
+			else { p = hist[k]; for (u32 j = 0; j < i; ++j) p += (mKey[j] == k) ? 1u : 0u; } // (rare: a body with more than 64 users in one task)
+			mPos[i] = p; mCnt[p] = (4u - (k & 3u));
+		}
 		__syncthreads();
 		// 5. extra-row offsets: exclusive scan of (count - 1) over the final positions (2 per lane)
 		{

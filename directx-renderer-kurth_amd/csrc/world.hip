@@ -1081,6 +1081,7 @@ int mi_snapshot_save(mi_world* world, void* buffer, uint64_t capacity)
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	BlobWriter out; serialize(*W, out);
 	if (W->lastError) return W->lastError;
+	W->refreshCounters();     // the last step is counted now (and has had its say on the number of partition phases), not at the next step:
 	W->clusterSortDue = true; // the restored world orders its bodies at its first step: so does this one at its next ...
 	if (!W->clusterPartsFixed) W->clusterParts = 3; // ... and both start from the default number of partition phases
 	if (!buffer || capacity < out.bytes.size()) { W->fail(MI_ERR_CAPACITY, "mi_snapshot_save: buffer too small (ask mi_snapshot_size)"); return MI_ERR_CAPACITY; }

@@ -124,3 +124,22 @@ def test_cluster_follow_c3_full_size(mi, oracle):
     st = g.stats()
     assert st["numFlowRecoveries"] == 0 and st["clusterTasks"][0] >= 100, st
     print("c3 full size:", {k: r[k] for k in ("num_pairs", "num_manifolds", "num_contacts", "vel_err", "pos_err")}, "tasks", st["clusterTasks"])
+
+
+@pytest.mark.parametrize("name, steps", [("c3_mid", 120), ("c4_small", 60)])
+def test_cluster_sweep_repeats_bit_identically(mi, name, steps):
+    """The sweep's schedule is built with atomics (append cursors, hash insertion); its RESULTS must not depend on how they land:
+    the task's manifolds are ordered by narrowphase slot before colouring, the order inside a colour is free, hand-over turns are
+    a function of the task structure.  Two runs of the same scene end bit-equal (what snapshot / restore and lockstep replicas rely on)."""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name(name)
+    out = []
+    for _ in range(2):
+        w = scene.instantiate(mi.World())
+        for _ in range(steps):
+            w.step_internal(scene.dt)
+        st = w.stats()
+        assert st["numFlowRecoveries"] == 0 and sum(st["clusterTasks"]) > 0
+        out.append((w.transforms(1), w.velocities()))
+        w.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
