@@ -120,6 +120,9 @@ __global__ void __launch_bounds__(256) k_cl_ranks(u32 nb, u32 numParts, const u3
 // first and gather in the low colours: a colour's sweep time is that of its longest manifold, and this keeps the 2-4-contact ones
 // (20 % of a mixed pile) out of most colours.  Then a pseudo-random priority (hash of the narrowphase slot and the round), then
 // the position inside the task, which makes the bid unique.
+// A phase may not have more tasks than the solve launch has workgroups (task t of a phase runs on workgroup (offset + t) % G, all
+// of them resident): when the pile outgrows "G tasks of the configured weight", the chunks grow instead.  cum[nb] = total weight.
+MI_DEV u32 clEffectiveWeight(u32 taskWeight, u32 totalWeight, u32 maxTasks) { u32 need = totalWeight / maxTasks + 1u; return need > taskWeight ? need : taskWeight; }
 MI_DEV u32 clBid(u32 slot, u32 count, u32 round, u32 i) { return (((4u - count) & 3u) << 22) | ((clHash(slot * 2654435761u + round) & 0x3FFu) << 12) | (i & 0xFFFu); } // 24 bits
 #define CL_SUBCOUNTERS 8u // a task's append cursor is split in 8 (by workgroup) so that ~650 returning atomics do not queue on one address
 
@@ -157,13 +160,13 @@ __global__ void __launch_bounds__(256) k_cl_joint_weights(u32 numJoints, const u
 	atomicAdd(&wsum[rank0[rep[table[i].z]]], CL_WEIGHT_JOINT);
 }
 // After phase 0's scan: every joint goes to the task of its island.
-__global__ void __launch_bounds__(256) k_cl_joint_assign(u32 numJoints, u32 taskWeight, const uint4* __restrict__ table, const u32* __restrict__ rank0, const u32* __restrict__ rep, const u32* __restrict__ cum,
+__global__ void __launch_bounds__(256) k_cl_joint_assign(u32 numJoints, u32 nb, u32 taskWeight, u32 maxTasks, const uint4* __restrict__ table, const u32* __restrict__ rank0, const u32* __restrict__ rep, const u32* __restrict__ cum,
 	u32* __restrict__ jointTask, u32* __restrict__ jointPos, u32* __restrict__ jointCount, u32* __restrict__ phaseMask, u32* __restrict__ status)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= numJoints) return;
 	uint4 e = table[i];
-	u32 t = cum[rank0[rep[e.z]]] / taskWeight;
+	u32 t = cum[rank0[rep[e.z]]] / clEffectiveWeight(taskWeight, cum[nb], maxTasks);
 	if (t >= CL_MAX_TASKS) { atomicOr(status, 1u); t = CL_MAX_TASKS - 1u; }
 	jointTask[i] = t;
 	jointPos[i] = atomicAdd(&jointCount[t], 1u);
@@ -176,11 +179,12 @@ __global__ void __launch_bounds__(256) k_cl_joint_scatter(u32 numJoints, const u
 }
 
 // Phase p: assign what is interior; what is left adds its weight to the next phase's curve, or (last partition) goes to the rest task.
-__global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 phase, u32 numParts, u32 taskWeight, const uint4* __restrict__ actIds,
+__global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 phase, u32 numParts, u32 taskWeight, u32 maxTasks, const uint4* __restrict__ actIds,
 	const u32* __restrict__ rank, const u32* __restrict__ cum, const u32* __restrict__ rankNext, u32* __restrict__ wsumNext,
 	u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask, u32* __restrict__ status, const u32* __restrict__ rep)
 {
 	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+	taskWeight = clEffectiveWeight(taskWeight, cum[nb], maxTasks);
 	const u32 entering = phase ? counters[CTR_CL_REMAIN + phase] : counters[CTR_NUM_ACTIVE];
 	const bool dumpAll = entering <= CL_REST_CAP && !rep; // few enough left: one task takes them all, later partitions stay empty (with joints, phase 0 keeps the contacts of an island next to its joints)
 	bool pending = j < counters[CTR_NUM_ACTIVE] && taskKey[j] == CL_UNASSIGNED;
@@ -1155,14 +1159,15 @@ void launch_cluster_build(World& w, u32 numPairs)
 	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.clJointCount.p, w.dCounters.p);
 	hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, rep, w.clWsum.p, w.clTaskKey.p);
 	if (nj) hipLaunchKernelGGL(k_cl_joint_weights, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clRank.p, rep, w.clWsum.p);
+	const u32 maxTasks = std::min<u32>(CL_MAX_TASKS, w.clusterBlocks) - std::min<u32>(8u, w.clusterBlocks / 2u); // per phase, with a margin for the chunks' rounding
 	for (u32 p = 0; p < parts; ++p)
 	{
 		u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
 		prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
-		hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, w.clusterTaskWeight, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
+		hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, w.clusterTaskWeight, maxTasks, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
 			w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, p == 0 ? rep : nullptr);
 		if (p == 0 && nj) // (cum still holds phase 0's scan)
-			hipLaunchKernelGGL(k_cl_joint_assign, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clusterTaskWeight, w.clJointTable.p, w.clRank.p, rep, w.clCum.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
+			hipLaunchKernelGGL(k_cl_joint_assign, dim3((nj + 255) / 256), block, 0, w.stream, nj, nb, w.clusterTaskWeight, maxTasks, w.clJointTable.p, w.clRank.p, rep, w.clCum.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
 	}
 	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, parts, w.clTaskCount.p, w.clTaskStart.p, nj ? w.clJointCount.p : (u32*)nullptr, nj ? w.clJointStart.p : (u32*)nullptr);
 	if (nj) hipLaunchKernelGGL(k_cl_joint_scatter, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTask.p, w.clJointPos.p, w.clJointStart.p, w.clJointList.p);
