@@ -57,7 +57,8 @@ World::World(int dev) : device(dev)
 	if (const char* e = getenv("MI_FLOW_TEST_ABORT")) flowTestAbortStep = (u32)atoi(e); // tests: make the cluster sweep of that internal step give up
 	if (const char* e = getenv("MI_CLUSTER_PARTS")) { clusterParts = std::min<u32>(CL_MAX_PARTS, std::max(1, atoi(e))); clusterPartsFixed = true; }
 	if (const char* e = getenv("MI_CLUSTER_SORT_INTERVAL")) clusterSortInterval = (u32)std::max(1, atoi(e));
-	if (const char* e = getenv("MI_CLUSTER_TASK")) clusterTaskWeight = 64u * (u32)std::max(16, atoi(e));   // manifolds per task
+	if (const char* e = getenv("MI_CLUSTER_TASK")) { clusterTaskWeight = 64u * (u32)std::max(16, atoi(e)); clusterTaskWeightLater = clusterTaskWeight; }  // manifolds per task
+	if (const char* e = getenv("MI_CLUSTER_TASK_LATER")) clusterTaskWeightLater = 64u * (u32)std::max(16, atoi(e)); // ... of the phases after the first
 	if (const char* e = getenv("MI_CLUSTER_SHIFT")) { int a = 0, b = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) for (u32 p = 1; p < CL_MAX_PARTS; ++p) { clusterShift[p][0] = (u32)a * p; clusterShift[p][1] = (u32)b * p; clusterShift[p][2] = (u32)c * p; } }
 	if (dCounters.p)
 	{
@@ -2197,13 +2198,14 @@ int mi_debug_read_body_state(mi_world* world, float* outCog4, float* outInvInert
 	d2h(W, outCog4, W->cog.p, sizeof(float4) * n); d2h(W, outInvInertia12, W->invIw.p, sizeof(float4) * 3 * n);
 	return W->lastError;
 }
-/* Developer timeline of the dataflow sweep: enable (allocates 256 B per manifold slot), step, then read 32 wall-clock stamps
- * (10 ns ticks) per schedule slot: when the slot's manifold finished iteration i. */
+/* Developer timeline of the cluster sweep: enable (allocates 16 rows of 32 stamps per workgroup of the solve launch), step, then read
+ * numSlots rows of 32 u64 (k_cl_solve documents the rows; wall-clock stamps are 10 ns ticks). */
 int mi_debug_flow_trace(mi_world* world, int enable, unsigned long long* out, uint32_t numSlots)
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
-	if (enable && W->flowTrace.cap < (size_t)W->pairCap * 32) { W->flowTrace.ensure((size_t)W->pairCap * 32, W->stream); MI_CHECK(hipMemsetAsync(W->flowTrace.p, 0, sizeof(u64) * W->pairCap * 32, W->stream)); }
-	if (out && W->flowTrace.p) d2h(W, out, W->flowTrace.p, sizeof(u64) * 32 * std::min<size_t>(numSlots, W->pairCap));
+	const size_t rows = (size_t)CL_MAX_TASKS * 16u;
+	if (enable && !W->flowTrace.p) { W->flowTrace.ensure(rows * 32, W->stream); MI_CHECK(hipMemsetAsync(W->flowTrace.p, 0, sizeof(u64) * rows * 32, W->stream)); }
+	if (out && W->flowTrace.p) d2h(W, out, W->flowTrace.p, sizeof(u64) * 32 * std::min<size_t>(numSlots, rows));
 	if (!enable) W->flowTrace.release();
 	return W->lastError;
 }

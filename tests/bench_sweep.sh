@@ -1,0 +1,9 @@
+mkdir -p gpurun_out/r02
+for L in 960 480 320; do
+MI_CLUSTER_TASK_LATER=$L timeout -k 10 200 python bench.py --no-cpu-baseline > gpurun_out/r02/bench_L$L.json 2>/dev/null || exit 1
+python - <<PY
+import json
+j=json.load(open("gpurun_out/r02/bench_L$L.json"))
+print($L, round(j["ms_per_step"],4), j["stage_ms"], j["config"]["solver"], j["config"]["recoveries"])
+PY
+done
