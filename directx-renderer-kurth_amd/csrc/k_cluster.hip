@@ -30,6 +30,9 @@ void prim_sort_pairs_u32(World& w, const u32* kin, u32* kout, const u32* vin, u3
 void prim_exclusive_scan_u32(World& w, const u32* in, u32* out, u32 n);
 
 #define CL_LANES 1024u                    // k_cl_color
+#define CL_TASKS_PER_PHASE 2u              // tasks of one phase a workgroup may run (LDS holds the bodies and meta of all its tasks)
+#define CL_MAX_LOCAL_TASKS 8u              // tasks of all phases per workgroup
+#define CL_WEIGHT_REG_LIMIT (64u * 1250u)  // chunk weight up to which a task's manifolds (almost always) fit two per lane
 #define CLS_LANES 512u                    // k_cl_solve: 8 waves, so that a lane may keep ...
 #define CLS_R 2u                          // ... the first contact row of this many manifolds in registers (256 VGPRs per lane at 2 waves per SIMD)
 #define CL_UNASSIGNED 0xFFFFFFFFu
@@ -122,7 +125,14 @@ __global__ void __launch_bounds__(256) k_cl_ranks(u32 nb, u32 numParts, const u3
 // the position inside the task, which makes the bid unique.
 // A phase may not have more tasks than the solve launch has workgroups (task t of a phase runs on workgroup (offset + t) % G, all
 // of them resident): when the pile outgrows "G tasks of the configured weight", the chunks grow instead.  cum[nb] = total weight.
-MI_DEV u32 clEffectiveWeight(u32 taskWeight, u32 totalWeight, u32 maxTasks) { u32 need = totalWeight / maxTasks + 1u; return need > taskWeight ? need : taskWeight; }
+MI_DEV u32 clEffectiveWeight(u32 taskWeight, u32 totalWeight, u32 maxTasks)
+{
+	u32 need = totalWeight / maxTasks + 1u;                                   // one task per workgroup ...
+	if (need <= taskWeight) return taskWeight;
+	if (need <= CL_WEIGHT_REG_LIMIT) return need;                             // ... as long as such a task still fits the lanes' registers,
+	u32 need2 = totalWeight / (CL_TASKS_PER_PHASE * maxTasks) + 1u;             // then up to CL_TASKS_PER_PHASE per workgroup (the later ones run from LDS)
+	return need2 > CL_WEIGHT_REG_LIMIT ? need2 : CL_WEIGHT_REG_LIMIT;
+}
 MI_DEV u32 clBid(u32 slot, u32 count, u32 round, u32 i) { return (((4u - count) & 3u) << 22) | ((clHash(slot * 2654435761u + round) & 0x3FFu) << 12) | (i & 0xFFFu); } // 24 bits
 #define CL_SUBCOUNTERS 8u // a task's append cursor is split in 8 (by workgroup) so that ~650 returning atomics do not queue on one address
 
@@ -731,7 +741,7 @@ MI_DEV void clSolveReg(float4* lds, const ClArgs& A, u32 rdA, u32 wrA, u32 rdB, 
 template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 {
 	extern __shared__ float4 lds[];
-	__shared__ ClLocal sTask[CL_MAX_PHASES];
+	__shared__ ClLocal sTask[CL_MAX_LOCAL_TASKS];
 	__shared__ u32 sNumTasks, sAbort;
 	const u32 tid = threadIdx.x, G = gridDim.x;
 	u32* status = A.counters + CTR_FLOW_STATUS;
@@ -746,26 +756,30 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 		for (u32 p = 0; p < CL_MAX_PHASES; ++p)
 		{
 			u32 tasksInPhase = A.counters[CTR_CL_NUM_TASKS + p];
-			if (tasksInPhase > G) bad = true;
-			// task t of phase p runs on workgroup (off + t) % G
+			if (tasksInPhase > CL_TASKS_PER_PHASE * G) bad = true;
+			// task t of phase p runs on workgroup (off + t) % G; a phase with more tasks than workgroups wraps around (its tasks share
+			// no body, so a workgroup may run two of them one after the other)
 			u32 t = (blockIdx.x + G - (off % G)) % G;
 			off += tasksInPhase;
-			if (t >= tasksInPhase) continue;
-			u32 key = p * CL_MAX_TASKS + t;
-			const ClTask* T = A.tasks + key;
-			const u32 tj = (A.jointClassStart && p == 0u) ? A.jointClassStart[(size_t)key * (CL_MAX_JOINT_CLASSES + 2u) + CL_MAX_JOINT_CLASSES] : 0u; // joints of the task
-			if (!T->count && !tj) continue;
-			ClLocal& L = sTask[nT];
-			L.first = T->first; L.count = T->count; L.numBodies = T->numBodies; L.numShared = T->numShared; L.numColors = T->numColors; L.serialStart = T->serialStart;
-			L.phase = p; L.key = key; L.sharedBase = T->sharedBase; L.numJoints = tj;
-			if (tj > CLS_LANES) bad = true; // one lane per joint
-			for (u32 c = 0; c <= CL_SERIAL_COLOR + 1u; ++c) L.colorStart[c] = T->colorStart[c];
-			L.bodyOff = used; used += 2u * L.numBodies;
-			L.infoOff = used * 4u; used += (3u * L.numBodies + 3u) / 4u;
-			L.inRegs = (nT == 0 && L.count <= CLS_LANES * CLS_R) ? 1u : 0u;
-			L.metaOff = used; if (!L.inRegs) used += 2u * L.count;
-			L.rowOff = 0; L.rowCap = 0;
-			++nT;
+			for (; t < tasksInPhase && !bad; t += G)
+			{
+				u32 key = p * CL_MAX_TASKS + t;
+				const ClTask* T = A.tasks + key;
+				const u32 tj = (A.jointClassStart && p == 0u) ? A.jointClassStart[(size_t)key * (CL_MAX_JOINT_CLASSES + 2u) + CL_MAX_JOINT_CLASSES] : 0u; // joints of the task
+				if (!T->count && !tj) continue;
+				if (nT == CL_MAX_LOCAL_TASKS) { bad = true; break; }
+				ClLocal& L = sTask[nT];
+				L.first = T->first; L.count = T->count; L.numBodies = T->numBodies; L.numShared = T->numShared; L.numColors = T->numColors; L.serialStart = T->serialStart;
+				L.phase = p; L.key = key; L.sharedBase = T->sharedBase; L.numJoints = tj;
+				if (tj > CLS_LANES || (tj && nT)) bad = true; // one lane per joint; joints run with the workgroup's first task only
+				for (u32 c = 0; c <= CL_SERIAL_COLOR + 1u; ++c) L.colorStart[c] = T->colorStart[c];
+				L.bodyOff = used; used += 2u * L.numBodies;
+				L.infoOff = used * 4u; used += (3u * L.numBodies + 3u) / 4u;
+				L.inRegs = (nT == 0 && L.count <= CLS_LANES * CLS_R) ? 1u : 0u;
+				L.metaOff = used; if (!L.inRegs) used += 2u * L.count;
+				L.rowOff = 0; L.rowCap = 0;
+				++nT;
+			}
 		}
 		// rows: whatever LDS is left, in task order (7 plane-rows of 16 B per row: 6 float4 + 1 float2 rounded up)
 		for (u32 k = 0; k < nT; ++k)
@@ -878,7 +892,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 	if (trace && tid == 0)
 	{
 		trace[15 * 32 + 1] = wall_clock64();
-		for (u32 k = 0; k < numTasks; ++k) { trace[15 * 32 + 2 + 4 * k] = sTask[k].count; trace[15 * 32 + 3 + 4 * k] = sTask[k].numColors; trace[15 * 32 + 4 + 4 * k] = sTask[k].numShared; trace[15 * 32 + 5 + 4 * k] = sTask[k].phase | (sTask[k].numBodies << 8) | ((u64)sTask[k].rowCap << 32); }
+		for (u32 k = 0; k < numTasks && k < 5u; ++k) { trace[15 * 32 + 2 + 4 * k] = sTask[k].count; trace[15 * 32 + 3 + 4 * k] = sTask[k].numColors; trace[15 * 32 + 4 + 4 * k] = sTask[k].numShared; trace[15 * 32 + 5 + 4 * k] = sTask[k].phase | (sTask[k].numBodies << 8) | ((u64)sTask[k].rowCap << 32); }
 	}
 
 	// ---- iterations ----
@@ -1012,7 +1026,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 					__syncthreads();
 				}
 			}
-			if (trace && tid == 0 && it - A.itBegin < 32u && k < 5u && !(k == 1 && false)) trace[(3 * k + 1) * 32 + (it - A.itBegin)] = wall_clock64();
+			if (trace && tid == 0 && it - A.itBegin < 32u && k < 5u) trace[(3 * k + 1) * 32 + (it - A.itBegin)] = wall_clock64();
 			// hand the shared bodies on
 			for (u32 l = tid; l < L.numShared; l += CLS_LANES)
 			{
@@ -1109,6 +1123,7 @@ bool cluster_available(World& w)
 		return false;
 	}
 	w.clusterLdsBytes = (u32)dyn; w.clusterBlocks = (u32)std::max(1, cus);
+	if (w.clusterBlocksLimit) w.clusterBlocks = std::min(w.clusterBlocks, w.clusterBlocksLimit); // MI_CLUSTER_BLOCKS (tests: a small launch, so that phases wrap around)
 	return true;
 }
 
@@ -1159,7 +1174,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.clJointCount.p, w.dCounters.p);
 	hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, rep, w.clWsum.p, w.clTaskKey.p);
 	if (nj) hipLaunchKernelGGL(k_cl_joint_weights, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clRank.p, rep, w.clWsum.p);
-	const u32 maxTasks = std::min<u32>(CL_MAX_TASKS, w.clusterBlocks) - std::min<u32>(8u, w.clusterBlocks / 2u); // per phase, with a margin for the chunks' rounding
+	const u32 maxTasks = std::min<u32>(CL_MAX_TASKS / CL_TASKS_PER_PHASE, w.clusterBlocks) - std::min<u32>(8u, w.clusterBlocks / 8u); // per phase, with a margin for the chunks' rounding
 	for (u32 p = 0; p < parts; ++p)
 	{
 		u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;

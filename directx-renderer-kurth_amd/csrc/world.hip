@@ -58,6 +58,7 @@ World::World(int dev) : device(dev)
 	if (const char* e = getenv("MI_CLUSTER_PARTS")) { clusterParts = std::min<u32>(CL_MAX_PARTS, std::max(1, atoi(e))); clusterPartsFixed = true; }
 	if (const char* e = getenv("MI_CLUSTER_SORT_INTERVAL")) clusterSortInterval = (u32)std::max(1, atoi(e));
 	if (const char* e = getenv("MI_CLUSTER_TASK")) { clusterTaskWeight = 64u * (u32)std::max(16, atoi(e)); clusterTaskWeightLater = clusterTaskWeight; }  // manifolds per task
+	if (const char* e = getenv("MI_CLUSTER_BLOCKS")) clusterBlocksLimit = (u32)std::max(1, atoi(e));
 	if (const char* e = getenv("MI_CLUSTER_TASK_LATER")) clusterTaskWeightLater = 64u * (u32)std::max(16, atoi(e)); // ... of the phases after the first
 	if (const char* e = getenv("MI_CLUSTER_SHIFT")) { int a = 0, b = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) for (u32 p = 1; p < CL_MAX_PARTS; ++p) { clusterShift[p][0] = (u32)a * p; clusterShift[p][1] = (u32)b * p; clusterShift[p][2] = (u32)c * p; } }
 	if (dCounters.p)
@@ -570,7 +571,8 @@ void World::recoverFlow()
 			hCounters[CTR_CL_STATUS], clusterParts, hCounters[CTR_CL_NUM_TASKS], hCounters[CTR_CL_NUM_TASKS + 1], hCounters[CTR_CL_NUM_TASKS + 2], hCounters[CTR_CL_NUM_TASKS + 3], hCounters[CTR_CL_NUM_TASKS + 4],
 			hCounters[CTR_CL_PHASE_COUNT], hCounters[CTR_CL_PHASE_COUNT + 1], hCounters[CTR_CL_PHASE_COUNT + 2], hCounters[CTR_CL_PHASE_COUNT + 3], hCounters[CTR_CL_PHASE_COUNT + 4], hCounters[CTR_NUM_ACTIVE],
 			hCounters[CTR_CL_REMAIN + 1], hCounters[CTR_CL_REMAIN + 2], hCounters[CTR_CL_REMAIN + 3], hCounters[CTR_CL_REMAIN + 4], hCounters[CTR_CL_REMAIN + 5]);
-	if ((why & 64u) && !(why & 1u)) { clusterCooldown = 4; if (!clusterPartsFixed && clusterParts < CL_MAX_PARTS) ++clusterParts; }
+	// (a world that keeps not fitting backs off: 4, 8, ... 256 steps of launch sweep between attempts)
+	if ((why & 64u) && !(why & 1u)) { clusterCooldown = std::min(256u, 4u << std::min(clusterFailStreak, 6u)); ++clusterFailStreak; if (!clusterPartsFixed && clusterParts < CL_MAX_PARTS) ++clusterParts; }
 	else clusterCooldown = 256;
 	coloringRounds = 64;
 	const size_t nb1 = (size_t)nb + 1;
@@ -634,6 +636,7 @@ void World::countPreviousStep()
 	stats.clusterSharedBodies = (had && lastStepCluster) ? hCounters[CTR_CL_SHARED] : 0; stats.clusterParts = lastStepCluster ? clusterParts : 0;
 	// Partition phases of the next step: one more when the rest task is filling up (it has hard limits), one fewer when the last
 	// one found nothing to do (each costs a sort of the bodies).
+	if (had && lastStepCluster) clusterFailStreak = 0; // (a give-up never gets here: recoverFlow clears lastStepCluster)
 	if (had && lastStepCluster && !clusterPartsFixed)
 	{
 		if (hCounters[CTR_CL_PHASE_COUNT + CL_MAX_PARTS] > 768u && clusterParts < CL_MAX_PARTS) ++clusterParts;
@@ -1085,6 +1088,7 @@ int mi_snapshot_save(mi_world* world, void* buffer, uint64_t capacity)
 	W->refreshCounters();     // the last step is counted now (and has had its say on the number of partition phases), not at the next step:
 	W->clusterSortDue = true; // the restored world orders its bodies at its first step: so does this one at its next ...
 	if (!W->clusterPartsFixed) W->clusterParts = 3; // ... and both start from the default number of partition phases
+	W->clusterCooldown = 0; W->clusterFailStreak = 0; // ... with the cluster sweep on
 	if (!buffer || capacity < out.bytes.size()) { W->fail(MI_ERR_CAPACITY, "mi_snapshot_save: buffer too small (ask mi_snapshot_size)"); return MI_ERR_CAPACITY; }
 	memcpy(buffer, out.bytes.data(), out.bytes.size());
 	return MI_OK;

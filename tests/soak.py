@@ -17,7 +17,7 @@ for i in range(steps):
     w.step_internal(scene.dt, 30)
     if i % 500 == 499:
         s = w.stats()
-        print("step", i + 1, "contacts", s["numContacts"], "colors", s["numColors"], "recoveries", s["numFlowRecoveries"], "elapsed %.1fs" % (time.time() - t0), flush=True)
+        print("step", i + 1, "contacts", s["numContacts"], "manifolds", s["numCollisions"], "colors", s["numColors"], "tasks", s["clusterTasks"], "recoveries", s["numFlowRecoveries"], "elapsed %.1fs" % (time.time() - t0), flush=True)
 w.synchronize()
 dt = time.time() - t0
 t = w.transforms(1); v = w.velocities(); s = w.stats()

@@ -73,6 +73,24 @@ def test_cluster_tiny_tasks(mi, oracle):
     assert most_tasks >= 40 and most_phases >= 3 and cluster_steps >= 60
 
 
+def test_cluster_two_tasks_per_phase_and_workgroup(mi, oracle):
+    """A launch of 8 workgroups on 20k bodies: the first phase has more tasks than workgroups, so it wraps around (a workgroup runs
+    two tasks of one phase one after the other, the second from LDS) — what a pile beyond ~250k manifolds does on the full chip."""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name("c3_mid")
+    g = _world(mi, scene, MI_CLUSTER_BLOCKS=8)
+    o = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_CUSTOM))
+    wrapped = 0
+    for i in range(120):
+        r = follow_step(g, o, scene.dt, 30)
+        assert r["pairs_equal"] and r["counts_equal"], i
+        assert r["vel_err"] <= 1e-4 * max(1.0, r["vel_scale"]), "step %d: velocity error %g" % (i, r["vel_err"])
+        st = g.stats()
+        wrapped += st["clusterTasks"][0] > 8
+    print("two tasks per phase: steps with a wrapped first phase:", wrapped, "of 120, recoveries", st["numFlowRecoveries"], "last", st["clusterTasks"], st["clusterManifolds"])
+    assert wrapped >= 10 and st["numFlowRecoveries"] <= 2
+
+
 def test_launch_sweep_follow(mi, oracle):
     """The fallback (global colouring, one launch per colour, MI_PHYSICS_NO_CLUSTER=1) against the oracle following its order."""
     from directx_renderer_kurth_amd import scenes
