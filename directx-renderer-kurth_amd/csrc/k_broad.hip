@@ -194,6 +194,8 @@ static void ensureTemp(World& w, size_t bytes)
 {
 	if (bytes > w.tempStorage.cap) w.tempStorage.ensure(bytes + bytes / 2 + 4096, w.stream);
 }
+// (Measured: forcing rocPRIM's one-sweep radix sort instead of the merge sort it picks below a million items is slower here: 100 k
+// cell hashes of 18 bits, broadphase stage 0.33 ms against 0.29 ms.)
 void prim_sort_pairs_u32(World& w, const u32* kin, u32* kout, const u32* vin, u32* vout, u32 n, u32 bits)
 {
 	if (!n) return;

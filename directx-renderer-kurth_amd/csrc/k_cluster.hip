@@ -227,7 +227,29 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 	{
 		u32 ph = key / CL_MAX_TASKS;
 		taskKey[j] = key;
-		taskPos[j] = atomicAdd(&taskCount[key * CL_SUBCOUNTERS + (blockIdx.x & (CL_SUBCOUNTERS - 1u))], 1u);
+		// append position: one atomic per (wave, task) instead of one per manifold.  The active list follows the narrowphase slots,
+		// i.e. the broadphase's cell order, so a wave's manifolds belong to very few tasks; returning atomics on one address are
+		// served one after the other (~0.2 us each), and a task used to get ~80 of them per sub-counter.
+		{
+			u32 pos = 0;
+			u64 todo = __ballot(1);
+			const u32 lane = threadIdx.x & 63u;
+			while (todo)
+			{
+				u32 leader = (u32)__ffsll((long long)todo) - 1u;
+				u32 k0 = __shfl(key, leader);
+				u64 same = __ballot(key == k0) & todo;
+				if (key == k0)
+				{
+					u32 base = 0;
+					if (lane == leader) base = atomicAdd(&taskCount[key * CL_SUBCOUNTERS + (blockIdx.x & (CL_SUBCOUNTERS - 1u))], (u32)__popcll(same));
+					base = __shfl(base, leader);
+					pos = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
+				}
+				todo &= ~same;
+			}
+			taskPos[j] = pos;
+		}
 		// (most bodies have the bit already from another manifold of theirs: look before the atomic)
 		if (da && !(__hip_atomic_load(&phaseMask[ids.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << ph))) atomicOr(&phaseMask[ids.x], 1u << ph);
 		if (db && !(__hip_atomic_load(&phaseMask[ids.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << ph))) atomicOr(&phaseMask[ids.y], 1u << ph);
@@ -308,7 +330,7 @@ static_assert(sizeof(ClTask) == 320, "task header");
 
 __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u32 nb, const u32* __restrict__ taskStart, u32* __restrict__ pre, const uint4* __restrict__ actIds,
 	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ bodyUsers, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ mExtra, u32* __restrict__ mRank, u32* __restrict__ sharedSlot,
-	const u32* __restrict__ jointStart, const u32* __restrict__ jointList, const uint4* __restrict__ jointTable, uint2* __restrict__ taskJoints, u32* __restrict__ jointClassStart)
+	const u32* __restrict__ jointStart, const u32* __restrict__ jointList, const uint4* __restrict__ jointTable, uint2* __restrict__ taskJoints, u32* __restrict__ jointClassStart, u64* __restrict__ trace)
 {
 	extern __shared__ u32 clds[];
 	u32* hKey = clds;                                   // [CL_HASH_SIZE] global id + 1, 0 = empty
@@ -322,9 +344,11 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 	u32* mSlot = mCnt + CL_TASK_MAX_MANIFOLDS;          // [..] narrowphase slot | contacts << 28 (the colouring rounds' priorities hash it)
 	u32* hist = mSlot + CL_TASK_MAX_MANIFOLDS;          // [264] per key, then cursors
 	u32* jHist = hist + 264;                            // [CL_MAX_JOINT_CLASSES + 1] joints per (type, colour) class, then cursors
-	__shared__ u32 sNumShared, sNumPrivate, sLeftA, sLeftB, sMaxColor, sScan[16], sSharedBase;
+	__shared__ u32 sNumShared, sNumPrivate, sMaxColor, sScan[16], sSharedBase;
 	const u32 tid = threadIdx.x;
 	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
+	// developer timeline (mi_debug_flow_trace): row 14 of the task's 16 rows = core-clock stamps of the stages below, [15] = colouring rounds
+#define CL_STAMP(I_) if (trace && tid == 0 && key < CL_MAX_TASKS) trace[((size_t)key * 16u + 14u) * 32u + (I_)] = clock64();
 
 	for (u32 key = blockIdx.x; key < totalKeys; key += gridDim.x)
 	{
@@ -341,10 +365,14 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 		for (u32 h = tid; h < 264u + CL_MAX_JOINT_CLASSES + 1u; h += CL_LANES) hist[h] = 0;
 		if (tid == 0) { sNumShared = 0; sNumPrivate = 0; sMaxColor = 0; }
 		__syncthreads();
+		CL_STAMP(0)
 		// 1. distinct dynamic bodies
+		// (the manifold's ids are fetched once, through two dependent global loads, and parked in LDS for the sort and step 2)
 		for (u32 i = tid; i < n; i += CL_LANES)
 		{
-			uint4 ids = actIds[pre[first + i]];
+			u32 pi = pre[first + i];
+			uint4 ids = actIds[pi];
+			mKey[i] = ids.x; mCnt[i] = ids.y; mAB[i] = pi; mSlot[i] = (ids.w & 0x0FFFFFFFu) | (ids.z << 28);
 			for (u32 e = 0; e < 2; ++e)
 			{
 				u32 g = e ? ids.y : ids.x;
@@ -375,12 +403,20 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			}
 		}
 		__syncthreads();
-		for (u32 h = tid; h < CL_HASH_SIZE; h += CL_LANES)
-			if (hKey[h])
-			{
-				bool shared = __popc(phaseMask[hKey[h] - 1u]) > 1;
-				hVal[h] = shared ? (atomicAdd(&sNumShared, 1u) | 0x80000000u) : atomicAdd(&sNumPrivate, 1u);
-			}
+		for (u32 h = tid; h < CL_HASH_SIZE; h += CL_LANES) // (uniform trip count: the ballots below see whole waves)
+		{
+			// local index = running count of the shared / private bodies: one LDS atomic per wave, not per body (same-address LDS
+			// atomics are served one lane at a time)
+			const bool has = hKey[h] != 0u;
+			const bool shared = has && __popc(phaseMask[hKey[h] - 1u]) > 1;
+			const u64 bs = __ballot(shared), bp = __ballot(has && !shared);
+			const u32 lane = tid & 63u;
+			u32 baseS = 0, baseP = 0;
+			if (lane == 0u) { if (bs) baseS = atomicAdd(&sNumShared, (u32)__popcll(bs)); if (bp) baseP = atomicAdd(&sNumPrivate, (u32)__popcll(bp)); }
+			baseS = __shfl(baseS, 0); baseP = __shfl(baseP, 0);
+			const u64 below = (1ull << lane) - 1ull;
+			if (has) hVal[h] = shared ? ((baseS + (u32)__popcll(bs & below)) | 0x80000000u) : baseP + (u32)__popcll(bp & below);
+		}
 		__syncthreads();
 		const u32 numShared = sNumShared, numBodies = sNumShared + sNumPrivate;
 		const bool tooMany = numBodies > CL_TASK_MAX_BODIES; // uniform
@@ -402,52 +438,63 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			}
 		for (u32 l = tid; l <= numBodies; l += CL_LANES) { mask[l] = 0ull; claim[l] = 0xFFFFFFFFu; }
 		__syncthreads();
+		CL_STAMP(1)
 		// 1b. The task's manifolds arrive in the order their append atomics landed.  The colouring below breaks bid ties by position, so
-		// the positions are made a function of the inputs first: bitonic sort by narrowphase slot (unique per manifold).  With that the
-		// whole schedule, and so every result, repeats from run to run (snapshot / restore continue bit-identically).  Stages that
-		// exchange inside 128 consecutive elements stay inside one wave and need no workgroup barrier.
+		// the positions are made a function of the inputs first: bitonic sort by {contact count, narrowphase slot} (unique per
+		// manifold).  With that the whole schedule, and so every result, repeats from run to run (snapshot / restore continue
+		// bit-identically).  Stages that exchange inside 128 consecutive elements stay inside one wave and need no workgroup barrier.
 		{
 			u32 m = 128u; while (m < n) m <<= 1;
-			u32* sKey = mSlot; u32* sVal = mPos;
-			for (u32 i = tid; i < m; i += CL_LANES)
-			{
-				u32 pi = (i < n) ? pre[first + i] : 0u;
-				sKey[i] = (i < n) ? (actIds[pi].w & 0x0FFFFFFFu) : 0xFFFFFFFFu; sVal[i] = pi;
-			}
+			// one 64-bit word per element {key, arrival index} (a stage is then one LDS round trip: two reads, compare, two writes);
+			// the words live in the colour-mask table, which the rounds need zeroed only afterwards
+			u64* sk = mask;
+			static_assert(CL_TASK_MAX_BODIES + 1u >= CL_TASK_MAX_MANIFOLDS, "the colour masks double as the sort's scratch");
+			for (u32 i = tid; i < m; i += CL_LANES) sk[i] = ((u64)(i < n ? mSlot[i] : 0xFFFFFFFFu) << 32) | i;
 			__syncthreads();
 			for (u32 k = 2u; k <= m; k <<= 1)
-				for (u32 j = k >> 1; j > 0u; j >>= 1)
+				for (u32 j = k >> 1, lj = 31u - (u32)__clz(k >> 1); j > 0u; j >>= 1, --lj) // j = 1 << lj (no integer division in the index arithmetic)
 				{
 					if (tid < (m >> 1))
 					{
-						u32 a = 2u * j * (tid / j) + (tid % j), b = a + j;
+						u32 a = ((tid >> lj) << (lj + 1u)) + (tid & (j - 1u)), b = a + j;
 						bool up = (a & k) == 0u;
-						u32 ka = sKey[a], kb = sKey[b];
-						if ((ka > kb) == up) { u32 va = sVal[a], vb = sVal[b]; sKey[a] = kb; sKey[b] = ka; sVal[a] = vb; sVal[b] = va; }
+						u64 ka = sk[a], kb = sk[b];
+						if ((ka > kb) == up) { sk[a] = kb; sk[b] = ka; }
 					}
 					if (j > 64u || (j == 1u && k >= 128u)) __syncthreads(); // the next stage (j / 2, or the next k's first) crosses the waves' 128-element blocks
 					else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 				}
 			__syncthreads();
-			for (u32 i = tid; i < n; i += CL_LANES) pre[first + i] = sVal[i]; // (read again when the final order is written out)
+			for (u32 i = tid; i < n; i += CL_LANES) { u64 e = sk[i]; mSlot[i] = (u32)(e >> 32); mPos[i] = (u32)e; }
+			__syncthreads();
+			for (u32 l = tid; l <= numBodies; l += CL_LANES) mask[l] = 0ull;
+			for (u32 i = tid; i < m; i += CL_LANES) mask[i] = 0ull; // (the scratch may reach beyond the bodies)
 		}
-		// 2. local ids of every manifold
-		for (u32 i = tid; i < n; i += CL_LANES)
+		CL_STAMP(2)
+		// 2. local ids of every manifold, in the sorted order (n <= 2 * CL_LANES: two per lane, gathered before anything is overwritten)
 		{
-			uint4 ids = actIds[mPos[i]];
-			u32 loc[2];
-			for (u32 e = 0; e < 2; ++e)
+			static_assert(CL_TASK_MAX_MANIFOLDS <= 2u * CL_LANES, "two manifolds per lane");
+			u32 gx[2], gy[2], gp[2];
+			for (u32 r = 0; r < 2u; ++r) { u32 i = tid + r * CL_LANES; if (i < n) { u32 o = mPos[i]; gx[r] = mKey[o]; gy[r] = mCnt[o]; gp[r] = mAB[o]; } }
+			__syncthreads();
+			for (u32 r = 0; r < 2u; ++r)
 			{
-				u32 g = e ? ids.y : ids.x;
-				loc[e] = CL_LOCAL_STATIC;
-				if (g >= nb) continue;
-				u32 h = clHash(g) & (CL_HASH_SIZE - 1u);
-				while (hKey[h] != g + 1u) h = (h + 1u) & (CL_HASH_SIZE - 1u);
-				loc[e] = hVal[h];
+				u32 i = tid + r * CL_LANES;
+				if (i >= n) continue;
+				u32 loc[2];
+				for (u32 e = 0; e < 2; ++e)
+				{
+					u32 g = e ? gy[r] : gx[r];
+					loc[e] = CL_LOCAL_STATIC;
+					if (g >= nb) continue;
+					u32 h = clHash(g) & (CL_HASH_SIZE - 1u);
+					while (hKey[h] != g + 1u) h = (h + 1u) & (CL_HASH_SIZE - 1u);
+					loc[e] = hVal[h];
+				}
+				mAB[i] = loc[0] | (loc[1] << 16);
+				mKey[i] = 0xFFFFFFFFu;
+				pre[first + i] = gp[r]; // (read again when the final order is written out)
 			}
-			mAB[i] = loc[0] | (loc[1] << 16);
-			mKey[i] = 0xFFFFFFFFu;
-			mSlot[i] = (ids.w & 0x0FFFFFFFu) | (ids.z << 28);
 		}
 		__syncthreads();
 		// 2b. the joints: local ids of their bodies, ordered by (type, colour) class (counting sort: class sizes, offsets, cursors)
@@ -481,34 +528,37 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			}
 			__syncthreads();
 		}
+		CL_STAMP(3)
 		// 3. colouring rounds.  A claim word holds {round, inverted bid}: a later round's bid beats any earlier one under atomicMax, so
-		// the claims need no clearing between rounds: two barriers per round (bid | decide).  The two sLeft counters alternate by round
-		// parity so that the next round's reset cannot overtake this round's readers.
+		// the claims need no clearing between rounds: two barriers per round (bid | decide; the second one also tells whether anybody
+		// is left).  No shared counters inside the rounds: a same-address LDS atomic from every lane costs more than the round itself.
 		for (u32 l = tid; l < numBodies; l += CL_LANES) claim[l] = 0u;
-		if (tid == 0) { sLeftA = 0; sLeftB = 0; }
 		__syncthreads();
+		// (a lane keeps its two manifolds' slot word, local body ids and colour in registers over the rounds: what it reads from LDS
+		// in a round is the claims and the colour masks only)
+		u32 rSlot[2], rAB[2], rKey[2];
+		for (u32 r = 0; r < 2u; ++r) { u32 i = tid + r * CL_LANES; rKey[r] = 0u; rSlot[r] = 0u; rAB[r] = 0u; if (i < n) { rSlot[r] = mSlot[i]; rAB[r] = mAB[i]; rKey[r] = 0xFFFFFFFFu; } }
 		for (u32 round = 0; ; ++round)
 		{
-			u32* leftNow = (round & 1u) ? &sLeftB : &sLeftA;
 			const bool lastRound = round >= 254u; // (the round tag has 8 bits: whoever is still uncoloured then goes to the serial tail)
-			for (u32 i = tid; i < n; i += CL_LANES)
+			u32 bid[2];
+			for (u32 r = 0; r < 2u; ++r)
 			{
-				if (mKey[i] != 0xFFFFFFFFu) continue;
-				u32 sc = mSlot[i];
-				u32 bid = ((round + 1u) << 24) | (0xFFFFFFu - clBid(sc & 0x0FFFFFFFu, sc >> 28, round, i));
-				u32 ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16;
-				if (la != CL_LOCAL_STATIC) atomicMax(&claim[la], bid);
-				if (lb != CL_LOCAL_STATIC) atomicMax(&claim[lb], bid);
+				if (rKey[r] != 0xFFFFFFFFu) continue;
+				u32 sc = rSlot[r];
+				bid[r] = ((round + 1u) << 24) | (0xFFFFFFu - clBid(sc & 0x0FFFFFFFu, sc >> 28, round, tid + r * CL_LANES));
+				u32 la = rAB[r] & 0xFFFFu, lb = rAB[r] >> 16;
+				if (la != CL_LOCAL_STATIC) atomicMax(&claim[la], bid[r]);
+				if (lb != CL_LOCAL_STATIC) atomicMax(&claim[lb], bid[r]);
 			}
 			__syncthreads();
 			u32 left = 0;
-			for (u32 i = tid; i < n; i += CL_LANES)
+			for (u32 r = 0; r < 2u; ++r)
 			{
-				if (mKey[i] != 0xFFFFFFFFu) continue;
-				u32 sc = mSlot[i], cnt = sc >> 28;
-				u32 bid = ((round + 1u) << 24) | (0xFFFFFFu - clBid(sc & 0x0FFFFFFFu, cnt, round, i));
-				u32 ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16;
-				bool won = (la == CL_LOCAL_STATIC || claim[la] == bid) && (lb == CL_LOCAL_STATIC || claim[lb] == bid);
+				if (rKey[r] != 0xFFFFFFFFu) continue;
+				u32 cnt = rSlot[r] >> 28;
+				u32 la = rAB[r] & 0xFFFFu, lb = rAB[r] >> 16;
+				bool won = (la == CL_LOCAL_STATIC || claim[la] == bid[r]) && (lb == CL_LOCAL_STATIC || claim[lb] == bid[r]);
 				if (!won && !lastRound) { ++left; continue; }
 				u64 used = (la != CL_LOCAL_STATIC ? mask[la] : 0ull) | (lb != CL_LOCAL_STATIC ? mask[lb] : 0ull);
 				u32 c = (won && ~used) ? (u32)__ffsll((long long)~used) - 1u : CL_SERIAL_COLOR;
@@ -516,16 +566,14 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 				{
 					if (la != CL_LOCAL_STATIC) mask[la] |= 1ull << c; // the only winner on this body in this round
 					if (lb != CL_LOCAL_STATIC) mask[lb] |= 1ull << c;
-					atomicMax(&sMaxColor, c + 1u);
 				}
-				mKey[i] = c * 4u + (4u - cnt);
+				rKey[r] = c * 4u + (4u - cnt);
 			}
-			if (left) atomicAdd(leftNow, left);
-			if (tid == 0) *((round & 1u) ? &sLeftA : &sLeftB) = 0; // the other counter: next round's
-			__syncthreads();
-			if (*leftNow == 0u) break;
+			if (!__syncthreads_or((int)left)) { if (trace && tid == 0 && key < CL_MAX_TASKS) trace[((size_t)key * 16u + 14u) * 32u + 15u] = round + 1u; break; }
 		}
+		for (u32 r = 0; r < 2u; ++r) { u32 i = tid + r * CL_LANES; if (i < n) mKey[i] = rKey[r]; }
 		__syncthreads();
+		CL_STAMP(4)
 		// 4. order by key: histogram, scan by one wave, cursors
 		for (u32 i = tid; i < n; i += CL_LANES) atomicAdd(&hist[mKey[i]], 1u);
 		__syncthreads();
@@ -538,6 +586,11 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			for (int o = 1; o < 64; o <<= 1) { u32 up = __shfl_up(incl, o); if ((int)tid >= o) incl += up; }
 			u32 run = incl - s;
 			for (u32 k = 0; k < 5u; ++k) { if (base + k < 260u) hist[base + k] = run; run += v[k]; }
+			// number of colours in use = highest non-empty colour below the serial class + 1
+			u32 top = 0;
+			for (u32 k = 0; k < 5u; ++k) if (v[k] && (base + k) / 4u < CL_SERIAL_COLOR) top = (base + k) / 4u + 1u;
+			for (int o = 32; o > 0; o >>= 1) top = max(top, (u32)__shfl_xor(top, o));
+			if (tid == 0) sMaxColor = top;
 		}
 		__syncthreads();
 		const u32 numColors = sMaxColor;
@@ -562,6 +615,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			mPos[i] = p; mCnt[p] = (4u - (k & 3u));
 		}
 		__syncthreads();
+		CL_STAMP(5)
 		// 5. extra-row offsets: exclusive scan of (count - 1) over the final positions (2 per lane)
 		{
 			u32 p0 = 2u * tid, e0 = (p0 < n) ? mCnt[p0] - 1u : 0u, e1 = (p0 + 1u < n) ? mCnt[p0 + 1u] - 1u : 0u;
@@ -578,6 +632,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			if (tid == CL_LANES - 1u) T->numRows = n + waveBase + incl;
 		}
 		__syncthreads();
+		CL_STAMP(6)
 		// 6. rank of every manifold among the users of each of its bodies, in position order (the dataflow sweep's turn numbers).
 		// Coloured manifolds: a colour occurs once per body, so the rank is the number of lower colours in the body's mask.  The serial
 		// tail (no colour left below 64: bodies with more than 64 users in this task) is walked by one lane in position order.
@@ -618,7 +673,9 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			mRank[first + p] = r;
 		}
 		__syncthreads();
+		CL_STAMP(7)
 	}
+#undef CL_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1189,7 +1246,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 	hipLaunchKernelGGL(k_cl_scatter, mgrid, block, 0, w.stream, w.dCounters.p, w.clTaskKey.p, w.clTaskPos.p, w.clTaskStart.p, w.clPre.p);
 	hipLaunchKernelGGL(k_cl_color, dim3(w.clusterBlocks), dim3(CL_LANES), clColorLdsBytes(), w.stream, w.dCounters.p, nb, w.clTaskStart.p, w.clPre.p, w.actIds.p,
 		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.clBodyUsers.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clExtra.p, w.clRankInfo.p, w.clSharedSlot.p,
-		nj ? w.clJointStart.p : (const u32*)nullptr, w.clJointList.p, w.clJointTable.p, w.clTaskJoints.p, w.clJointClassStart.p);
+		nj ? w.clJointStart.p : (const u32*)nullptr, w.clJointList.p, w.clJointTable.p, w.clTaskJoints.p, w.clJointClassStart.p, w.flowTrace.p);
 }
 
 // Iterations [itBegin, itEnd) of the contact sweep in one launch.

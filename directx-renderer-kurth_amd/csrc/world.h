@@ -172,16 +172,12 @@ struct World
 	DevBuf<uint4> actIds;                 // active manifolds: (bodyA, bodyB, count, slot)
 	DevBuf<u32> epaList; DevBuf<float4> gjkSimplex; // GJK hits -> EPA work list (9 float4 per hit)
 	DevBuf<float4> rowPlanes, rowShared; DevBuf<float2> rowLambda; DevBuf<uint4> rowIds;
-	DevBuf<u64> flow;                     // dataflow sweep: 8 x u64 per body {fp32 value, turn}
-	DevBuf<u32> regMask, mRegion, mRegionSorted, flowOrder, regionHist; // XCD regions: per-body region set, per-slot region, region-major slot order
-	bool regionsReady = false, useFlowRegions = false; u32 flowRegions = 1; // XCD regions: MI_FLOW_REGIONS=1 (no measured gain yet)
-	u32 flowEagerMax = 131072;            // up to this many manifolds every poll fetches both record halves (MI_FLOW_EAGER)
-	u32 flowMaxManifolds = 0xFFFFFFFFu;   // the dataflow kernel takes the colours at the end of the schedule holding at most this many manifolds, launches the rest (MI_FLOW_MAX; default: everything)
+	DevBuf<u64> flow;                     // cluster sweep: 32-byte hand-over record per (phase, shared body): two tagged 16-byte halves
 	// cluster sweep (k_cluster.hip)
 	bool validate = false;                // MI_PHYSICS_VALIDATE=1 / mi_enable_validation: NaN / Inf guard after every stage (the reference's VALIDATE macros, physics.cpp:807-926)
 	bool useCluster = true;               // MI_PHYSICS_NO_CLUSTER=1: launch-per-colour sweep only
 	bool lastStepCluster = false, backupVelocities = false;
-	u32 clusterBlocksLimit = 0, clusterFailStreak = 0, clusterParts = 3, clusterTaskWeight = 64u * 960u, clusterTaskWeightLater = 64u * 960u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
+	u32 clusterBlocksLimit = 0, clusterFailStreak = 0, clusterParts = 3, clusterTaskWeight = 64u * 1200u, clusterTaskWeightLater = 64u * 960u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
 	bool clusterPartsFixed = false;       // MI_CLUSTER_PARTS given: no adaptation
 	bool clusterSortDue = true; u32 clusterSortAge = 0, clusterSortInterval = 8, clusterSortBodies = 0; // body order along the curves: refreshed every few steps (MI_CLUSTER_SORT_INTERVAL)
 	u32 clusterLdsBytes = 0, clusterBlocks = 0, clusterCooldown = 0;
@@ -193,15 +189,12 @@ struct World
 	bool useClusterJoints = true;         // MI_CLUSTER_NO_JOINTS=1: joints keep their per-colour launches (one cluster launch per iteration then)
 	u32 clNumJoints = 0, clNumJointClasses = 0; bool clJointsInCluster = false; // false: more (type, colour) classes than the kernel's table: joints keep their launches
 	DevBuf<u64> flowTrace;                // developer timeline (mi_debug_flow_trace): 32 x u64 per slot, allocated on request only
-	u32 flowEpoch = 0, flowMaxBlocks[2] = { 0, 0 };
-	bool useFlow = true;                  // MI_PHYSICS_NO_FLOW=1: launch-per-colour sweep only
+	u32 flowEpoch = 0;
 	// Safety net of the persistent kernels: if one gives up waiting (only possible when the GPU is shared with another persistent
 	// kernel), the step's velocity integration is skipped on the device and the host redoes solve + integration with the launch
 	// sweep from the saved pre-solve velocities, at the next point where it synchronises anyway.
-	DevBuf<float4> velBackup; bool flowPending = false; float pendingDt = 0.f; u32 pendingIters = 0, flowCooldown = 0, flowTestAbortStep = ~0u;
+	DevBuf<float4> velBackup; bool flowPending = false; float pendingDt = 0.f; u32 pendingIters = 0, flowTestAbortStep = ~0u;
 	void recoverFlow(); int resolvePendingFlow();
-	u32 flowHopTicks = 100, flowBackoffCap = 64, flowPredictFrac = 192; // poll pacing: 10 ns ticks; fraction (/256) of the iteration period slept through (MI_FLOW_HOP / _CAP / _PREDICT)
-	u32 flowHopTicksLarge = 220;          // assumed hand-over time above flowEagerMax manifolds: measured 2.2 us there, ~1 us in small worlds (MI_FLOW_HOP_LARGE)
 	// force fields, triggers, events
 	DevBuf<float4> fieldForce;            // per field: world-space force (localized fields only; global ones are summed on the host into globalForce)
 	DevBuf<u32> fieldMask; u32 fieldWords = 0; // per body: bit f set = inside localized field f this step (set by k_zone_overlap, consumed + cleared by k_apply_fields)
@@ -272,7 +265,6 @@ void launch_collision_events(World& w, u32 numPairs);      // begin / end events
 void launch_coloring(World& w, u32 numPairs);
 void launch_contact_init(World& w, u32 numPairs, float dt);
 void launch_solve_contacts_iteration(World& w, const u32* gridBlocks, u32 numColors, u32 firstTail, bool serialBucket);
-void launch_solve_flow(World& w, u32 numManifolds, u32 itBegin, u32 itEnd, u32 firstColor);
 bool cluster_available(World& w);                          // sets up the cluster kernels' LDS budget once; false = this device cannot run them
 void launch_active_list(World& w, u32 numPairs);           // manifolds with contacts -> actIds (no colours)
 void launch_cluster_build(World& w, u32 numPairs);         // body order, tasks, local colouring, final slot order (k_cluster.hip)

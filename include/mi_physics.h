@@ -44,7 +44,7 @@ typedef struct mi_physics_settings
 	uint32_t frameRate;                    /* 120 */
 	uint32_t maxPhysicsIterationsPerFrame; /* 4 */
 	uint32_t numRigidSolverIterations;     /* 30 */
-	uint32_t numClothVelocityIterations, numClothPositionIterations, numClothDriftIterations; /* accepted, unused (cloth is out of scope) */
+	uint32_t numClothVelocityIterations, numClothPositionIterations, numClothDriftIterations; /* iteration counts of the cloth solver (cloth.cpp:331-347) */
 	uint32_t simdBroadPhase, simdNarrowPhase, simdConstraintSolver;                           /* accepted, unused: there is one (HIP) path */
 } mi_physics_settings;
 

@@ -48,3 +48,12 @@ for p in np.unique(ph_all[has]):
     q = has & (ph_all == p)
     a = us(raw[q, 0, 10]); c = us(raw[q, 1, 10]); a11 = us(raw[q, 0, 11])
     print("phase %d it10: acquired min %.2f med %.2f max %.2f | colours done min %.2f med %.2f max %.2f | it11 acquired min %.2f max %.2f" % (p, a.min(), np.median(a), a.max(), c.min(), np.median(c), c.max(), a11.min(), a11.max()))
+# k_cl_color's stages (row 14 of each phase-0 task: core-clock stamps; [15] = colouring rounds)
+c = raw[:, 14, :]
+ok = c[:, 7] > 0
+if ok.any():
+    d = np.diff(c[ok, :8], axis=1) / 2400.0  # us at ~2.4 GHz
+    names = ["bodies->hash", "sort by slot", "local ids (+joints)", "colouring rounds", "order by key", "row offsets", "ranks + output"]
+    print("k_cl_color per phase-0 task (%d tasks): total median %.1f us max %.1f us; colouring rounds median %d max %d" % (ok.sum(), np.median(d.sum(axis=1)), d.sum(axis=1).max(), np.median(c[ok, 15]), c[ok, 15].max()))
+    for i, n in enumerate(names):
+        print("   %-22s median %6.2f us  max %6.2f us" % (n, np.median(d[:, i]), d[:, i].max()))

@@ -6,7 +6,7 @@ rows = []
 for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-flow = [i for i, r in enumerate(rows) if "k_solve_flow" in r[2] or "k_solve_color" in r[2]]
+flow = [i for i, r in enumerate(rows) if "k_cl_solve" in r[2] or "k_solve_color" in r[2]]
 # a step = from one k_build_colliders to the next
 starts = [i for i, r in enumerate(rows) if "k_build_colliders" in r[2]]
 starts = starts[-(steps + 1):]
