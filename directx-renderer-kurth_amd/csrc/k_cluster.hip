@@ -794,6 +794,38 @@ MI_DEV void clSolveReg(float4* lds, const ClArgs& A, u32 rdA, u32 wrA, u32 rdB, 
 	lds[wrB] = make_float4(vB.x, vB.y, vB.z, invMassB); lds[wrB + 1] = make_float4(wB.x, wB.y, wB.z, 0.f);
 }
 
+// A manifold of the workgroup's SECOND task: its rows all live in LDS (or, beyond the budget, in global memory), but what a lane needs to
+// find them — body addresses, key, shared normal — sits in its registers like the first task's, so a colour step is ONE LDS round trip
+// (bodies and first row together) instead of the generic path's chain task record -> meta -> bodies / rows.
+MI_DEV void clSolveLds(float4* lds, const ClArgs& A, u32 rdA, u32 wrA, u32 rdB, u32 wrB, u32 keyExtra, float4 sh, u32 rowBase, u32 rowOff, u32 rowCap, u32 slot)
+{
+	float4 a0 = lds[rdA], a1 = lds[rdA + 1], b0 = lds[rdB], b1 = lds[rdB + 1];
+	V3 vA = v3f4(a0), wA = v3f4(a1), vB = v3f4(b0), wB = v3f4(b1);
+	float invMassA = a0.w, invMassB = b0.w;
+	V3 n = v3(sh.x, sh.y, sh.z);
+	float friction = sh.w;
+	u32 count = 4u - (keyExtra & 3u);
+	for (u32 k = 0; k < count; ++k)
+	{
+		u32 row = rowBase + k;
+		ContactRow cur;
+		if (row < rowCap)
+		{
+			clLoadRowLds(cur, lds, rowOff, rowCap, row);
+			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
+			clStoreLambdaLds(lds, rowOff, rowCap, row, cur.lam);
+		}
+		else // beyond the LDS budget: streamed from global memory every iteration
+		{
+			loadRow(cur, k, slot, A.rowCap, A.rowPlanes, A.rowLambda);
+			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
+			A.rowLambda[(size_t)k * A.rowCap + slot] = cur.lam;
+		}
+	}
+	lds[wrA] = make_float4(vA.x, vA.y, vA.z, invMassA); lds[wrA + 1] = make_float4(wA.x, wA.y, wA.z, 0.f);
+	lds[wrB] = make_float4(vB.x, vB.y, vB.z, invMassB); lds[wrB + 1] = make_float4(wB.x, wB.y, wB.z, 0.f);
+}
+
 // JOINTS: the instantiation for worlds whose joints run inside the sweep (its extra registers and code stay out of the other one).
 template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(ClArgs A)
 {
@@ -927,6 +959,17 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 	const u32 rdA1 = (regAB1 & 0xFFFFu) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB1 & 0xFFFFu), wrA1 = (regAB1 & 0xFFFFu) == CL_LOCAL_STATIC ? sinkRec : rdA1;
 	const u32 rdB1 = (regAB1 >> 16) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB1 >> 16), wrB1 = (regAB1 >> 16) == CL_LOCAL_STATIC ? sinkRec : rdB1;
 	const u32 rowOff0 = __builtin_amdgcn_readfirstlane(sTask[0].rowOff), rowCap0 = __builtin_amdgcn_readfirstlane(sTask[0].rowCap), first0 = __builtin_amdgcn_readfirstlane(sTask[0].first);
+	// the workgroup's second task, if it has at most one manifold per lane: this lane's manifold of it (position = lane)
+	const bool second = !JOINTS && numTasks > 1u && !sTask[1].inRegs && sTask[1].count <= CLS_LANES;
+	u32 s2KE = 0xFFFFFFFFu, s2rdA = zeroRec, s2wrA = sinkRec, s2rdB = zeroRec, s2wrB = sinkRec, s2rowBase = 0; float4 s2Sh = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (second && tid < sTask[1].count)
+	{
+		const u32 slot = sTask[1].first + tid, ab = A.mLocal[slot], key = A.mKeySorted[slot], extra = A.mExtra[slot], off1 = sTask[1].bodyOff;
+		s2KE = key | (extra << 10); s2Sh = A.rowShared[slot]; s2rowBase = tid + extra;
+		if ((ab & 0xFFFFu) != CL_LOCAL_STATIC) { s2rdA = off1 + 2u * (ab & 0xFFFFu); s2wrA = s2rdA; }
+		if ((ab >> 16) != CL_LOCAL_STATIC) { s2rdB = off1 + 2u * (ab >> 16); s2wrB = s2rdB; }
+	}
+	const u32 rowOff1 = second ? __builtin_amdgcn_readfirstlane(sTask[1].rowOff) : 0u, rowCap1 = second ? __builtin_amdgcn_readfirstlane(sTask[1].rowCap) : 0u, first1 = second ? __builtin_amdgcn_readfirstlane(sTask[1].first) : 0u;
 	// this lane's joint (first task only, phase 0): class, update record, the two bodies as LDS addresses and as global ids (inverse inertia)
 	u32 jClass = 0xFFFFFFFFu, jType = 0, jA = 0, jB = 0, jRdA = zeroRec, jWrA = sinkRec, jRdB = zeroRec, jWrB = sinkRec; float* jRec = nullptr;
 	const u32 numJoints0 = (JOINTS && sTask[0].phase == 0u) ? sTask[0].numJoints : 0u;
@@ -1059,6 +1102,21 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 				{
 					if (tid == sp) clSolveReg(lds, A, rdA0, wrA0, rdB0, wrB0, regKE0, regSh0, regRow0, rowOff0, rowCap0, first0 + tid);
 					if (tid + CLS_LANES == sp) clSolveReg(lds, A, rdA1, wrA1, rdB1, wrB1, regKE1, regSh1, regRow1, rowOff0, rowCap0, first0 + tid + CLS_LANES);
+					__syncthreads();
+				}
+			}
+			else if (second && k == 1u)
+			{
+				const u32 col = (s2KE & 0x3FFu) >> 2; // 255 = no manifold
+				const u32 numColors = __builtin_amdgcn_readfirstlane(L.numColors), serialStart = __builtin_amdgcn_readfirstlane(L.serialStart), taskCount = __builtin_amdgcn_readfirstlane(L.count);
+				for (u32 c = 0; c < numColors; ++c)
+				{
+					if (col == c) clSolveLds(lds, A, s2rdA, s2wrA, s2rdB, s2wrB, s2KE, s2Sh, s2rowBase, rowOff1, rowCap1, first1 + tid);
+					__syncthreads();
+				}
+				for (u32 sp = serialStart; sp < taskCount; ++sp) // the serial tail: one manifold per step
+				{
+					if (tid == sp) clSolveLds(lds, A, s2rdA, s2wrA, s2rdB, s2wrB, s2KE, s2Sh, s2rowBase, rowOff1, rowCap1, first1 + tid);
 					__syncthreads();
 				}
 			}
