@@ -1038,7 +1038,7 @@ __global__ void __launch_bounds__(256) k_gjk(u32* __restrict__ counters, const u
 // Phase 2: EPA (one wave per hit, polytope in LDS) + face clipping (lane 0) for every GJK hit.  Waves stride over the work list.
 #define EPA_WAVES_PER_BLOCK 4
 template <int FAMILY>
-__global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) k_epa(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
+__global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(FAMILY == 0 ? 4 : 2, FAMILY == 0 ? 4 : 3))) k_epa(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
 	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, const u32* __restrict__ epaList, const float4* __restrict__ gjkSimplex,
 	const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts, u32 listCap)
 {
