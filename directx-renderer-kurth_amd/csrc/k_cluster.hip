@@ -134,6 +134,7 @@ MI_DEV u32 clEffectiveWeight(u32 taskWeight, u32 totalWeight, u32 maxTasks)
 	return need2 > CL_WEIGHT_REG_LIMIT ? need2 : CL_WEIGHT_REG_LIMIT;
 }
 MI_DEV u32 clBid(u32 slot, u32 count, u32 round, u32 i) { return (((4u - count) & 3u) << 22) | ((clHash(slot * 2654435761u + round) & 0x3FFu) << 12) | (i & 0xFFFu); } // 24 bits
+#define CL_REMAIN_SUBS 64u // the 'still unassigned after phase p' count is kept in 64 partial counters: ~2000 workgroups adding to ONE word queue up behind each other
 #define CL_SUBCOUNTERS 8u // a task's append cursor is split in 8 (by workgroup) so that ~650 returning atomics do not queue on one address
 
 // Everything the assignment accumulates into, cleared in one launch.
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(256) k_cl_clear(u32 nb1, u32* __restrict__ wsu
 	if (i < CL_MAX_TASKS) jointCount[i] = 0;
 	if (i < CL_MAX_PARTS * nb1) wsum[i] = 0;
 	if (i < nb1) phaseMask[i] = 0;
-	if (i < CL_MAX_PHASES * CL_MAX_TASKS * CL_SUBCOUNTERS) taskCount[i] = 0;
+	if (i < CL_MAX_PHASES * CL_MAX_TASKS * CL_SUBCOUNTERS + 6u * CL_REMAIN_SUBS) taskCount[i] = 0; // (+ the split 'still unassigned' counters behind the task counters)
 	if (i < 7u) counters[CTR_CL_STATUS + i] = 0;  // status, shared bodies, manifolds per phase
 	if (i < 6u) counters[CTR_CL_REMAIN + i] = 0;
 }
@@ -195,7 +196,16 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 {
 	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
 	taskWeight = clEffectiveWeight(taskWeight, cum[nb], maxTasks);
-	const u32 entering = phase ? counters[CTR_CL_REMAIN + phase] : counters[CTR_NUM_ACTIVE];
+	u32* remainSub = taskCount + CL_MAX_PHASES * CL_MAX_TASKS * CL_SUBCOUNTERS;
+	__shared__ u32 sEntering;
+	if (threadIdx.x < 64u)
+	{
+		u32 v = phase ? remainSub[phase * CL_REMAIN_SUBS + threadIdx.x] : 0u;
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+		if (threadIdx.x == 0) sEntering = phase ? v : counters[CTR_NUM_ACTIVE];
+	}
+	__syncthreads();
+	const u32 entering = sEntering;
 	const bool dumpAll = entering <= CL_REST_CAP && !rep; // few enough left: one task takes them all, later partitions stay empty (with joints, phase 0 keeps the contacts of an island next to its joints)
 	bool pending = j < counters[CTR_NUM_ACTIVE] && taskKey[j] == CL_UNASSIGNED;
 	u32 key = CL_UNASSIGNED;
@@ -221,7 +231,7 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 	}
 	bool left = pending && key == CL_UNASSIGNED;
 	u32 numLeft = (u32)__syncthreads_count(left); // one atomic per workgroup
-	if (threadIdx.x == 0 && numLeft) atomicAdd(&counters[CTR_CL_REMAIN + phase + 1u], numLeft);
+	if (threadIdx.x == 0 && numLeft) atomicAdd(&remainSub[(phase + 1u) * CL_REMAIN_SUBS + (blockIdx.x & (CL_REMAIN_SUBS - 1u))], numLeft);
 	if (!pending) return;
 	if (key != CL_UNASSIGNED)
 	{
@@ -231,23 +241,23 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 		// i.e. the broadphase's cell order, so a wave's manifolds belong to very few tasks; returning atomics on one address are
 		// served one after the other (~0.2 us each), and a task used to get ~80 of them per sub-counter.
 		{
-			u32 pos = 0;
-			u64 todo = __ballot(1);
+			// groups of equal keys first (ballots only), then ALL the groups' leaders issue their atomics together: one round trip
+			// to the memory-side atomic unit per wave, not one per distinct key
+			u64 todo = __ballot(1), mine = 0;
 			const u32 lane = threadIdx.x & 63u;
 			while (todo)
 			{
 				u32 leader = (u32)__ffsll((long long)todo) - 1u;
 				u32 k0 = __shfl(key, leader);
 				u64 same = __ballot(key == k0) & todo;
-				if (key == k0)
-				{
-					u32 base = 0;
-					if (lane == leader) base = atomicAdd(&taskCount[key * CL_SUBCOUNTERS + (blockIdx.x & (CL_SUBCOUNTERS - 1u))], (u32)__popcll(same));
-					base = __shfl(base, leader);
-					pos = base + (u32)__popcll(same & ((1ull << lane) - 1ull));
-				}
+				if (key == k0) mine = same;
 				todo &= ~same;
 			}
+			const u32 myLeader = (u32)__ffsll((long long)mine) - 1u;
+			u32 base = 0;
+			if (lane == myLeader) base = atomicAdd(&taskCount[key * CL_SUBCOUNTERS + (blockIdx.x & (CL_SUBCOUNTERS - 1u))], (u32)__popcll(mine));
+			base = __shfl(base, myLeader);
+			u32 pos = base + (u32)__popcll(mine & ((1ull << lane) - 1ull));
 			taskPos[j] = pos;
 		}
 		// (most bodies have the bit already from another manifold of theirs: look before the atomic)
@@ -297,6 +307,7 @@ __global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters,
 	}
 	const u32 totalManifolds = taskStart[total];
 	if (t < CL_MAX_PHASES) counters[CTR_CL_NUM_TASKS + t] = lastTask[t];
+	if (t < 6u) { u32 v = 0; for (u32 k = 0; k < CL_REMAIN_SUBS; ++k) v += taskCount[total + t * CL_REMAIN_SUBS + k]; counters[CTR_CL_REMAIN + t] = v; } // for the host's statistics / phase-count adaptation
 	if (t == 0)
 	{
 		counters[CTR_NUM_MANIFOLDS] = totalManifolds;
@@ -1253,7 +1264,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 	w.clRank.ensure((size_t)P * nb1, w.stream); w.clSharedSlot.ensure((size_t)CL_MAX_PHASES * nb1, w.stream); w.clWsum.ensure(P * nb1, w.stream); w.clCum.ensure(nb1, w.stream); w.clPhaseMask.ensure(nb1, w.stream); }
 	w.clTaskKey.ensure(w.pairCap, w.stream); w.clTaskPos.ensure(w.pairCap, w.stream); w.clPre.ensure(w.pairCap, w.stream); w.clLocal.ensure(w.pairCap, w.stream); w.clExtra.ensure(w.pairCap, w.stream); w.clRankInfo.ensure(w.pairCap, w.stream);
 	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
-	w.clTaskCount.ensure(totalKeys * CL_SUBCOUNTERS, w.stream); w.clTaskStart.ensure(totalKeys * CL_SUBCOUNTERS + 1, w.stream);
+	w.clTaskCount.ensure(totalKeys * CL_SUBCOUNTERS + 6u * CL_REMAIN_SUBS, w.stream); w.clTaskStart.ensure(totalKeys * CL_SUBCOUNTERS + 1, w.stream);
 	w.clTasks.ensure((size_t)totalKeys * sizeof(ClTask), w.stream); w.clBodyList.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream); w.clBodyUsers.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream);
 	if (w.lastError) return;
 
@@ -1278,7 +1289,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 	w.clusterSortAge++;
 	// tasks
 	const u32 parts = w.clusterParts;
-	u32 clearItems = std::max<u32>((u32)(CL_MAX_PARTS * nb1), totalKeys * CL_SUBCOUNTERS);
+	u32 clearItems = std::max<u32>((u32)(CL_MAX_PARTS * nb1), totalKeys * CL_SUBCOUNTERS + 6u * CL_REMAIN_SUBS);
 	const bool withJoints = cluster_solves_joints(w);
 	const u32* rep = withJoints ? w.clRep.p : nullptr;
 	const u32 nj = withJoints ? w.clNumJoints : 0u;
