@@ -981,6 +981,13 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 		if ((ab >> 16) != CL_LOCAL_STATIC) { s2rdB = off1 + 2u * (ab >> 16); s2wrB = s2rdB; }
 	}
 	const u32 rowOff1 = second ? __builtin_amdgcn_readfirstlane(sTask[1].rowOff) : 0u, rowCap1 = second ? __builtin_amdgcn_readfirstlane(sTask[1].rowCap) : 0u, first1 = second ? __builtin_amdgcn_readfirstlane(sTask[1].first) : 0u;
+	// first of the register task's trailing colours that one wave runs without barriers (see the colour loop)
+	u32 tailStart0 = sTask[0].numColors;
+	if (sTask[0].inRegs && sTask[0].serialStart > 0u) { const u32 lastBlock = (sTask[0].serialStart - 1u) >> 6; while (tailStart0 > 0u && (sTask[0].colorStart[tailStart0 - 1u] >> 6) == lastBlock) --tailStart0; }
+	tailStart0 = __builtin_amdgcn_readfirstlane(tailStart0);
+	u32 tailStart1 = second ? sTask[1].numColors : 0u;
+	if (second && sTask[1].serialStart > 0u) { const u32 lastBlock = (sTask[1].serialStart - 1u) >> 6; while (tailStart1 > 0u && (sTask[1].colorStart[tailStart1 - 1u] >> 6) == lastBlock) --tailStart1; }
+	tailStart1 = __builtin_amdgcn_readfirstlane(tailStart1);
 	// this lane's joint (first task only, phase 0): class, update record, the two bodies as LDS addresses and as global ids (inverse inertia)
 	u32 jClass = 0xFFFFFFFFu, jType = 0, jA = 0, jB = 0, jRdA = zeroRec, jWrA = sinkRec, jRdB = zeroRec, jWrB = sinkRec; float* jRec = nullptr;
 	const u32 numJoints0 = (JOINTS && sTask[0].phase == 0u) ? sTask[0].numJoints : 0u;
@@ -1102,12 +1109,33 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 				const u32 numColors = __builtin_amdgcn_readfirstlane(L.numColors), serialStart = __builtin_amdgcn_readfirstlane(L.serialStart), taskCount = __builtin_amdgcn_readfirstlane(L.count);
 				const bool stamp = trace && tid == 0 && it == A.itBegin + 10u && k == 0;
 				if (stamp) trace[5 * 32] = clock64();
-				for (u32 c = 0; c < numColors; ++c)
+				// The last colours hold a handful of manifolds (the busiest body's last users).  Those whose positions all fall into
+				// ONE 64-position block belong to one wave (and one register set): that wave runs them back to back, in program
+				// order, without the workgroup barrier in between (LDS serves a wave's accesses in order).
+				const u32 tailStart = tailStart0;
+				for (u32 c = 0; c < tailStart; ++c)
 				{
 					if (col0 == c) clSolveReg(lds, A, rdA0, wrA0, rdB0, wrB0, regKE0, regSh0, regRow0, rowOff0, rowCap0, first0 + tid);
 					if (col1 == c) clSolveReg(lds, A, rdA1, wrA1, rdB1, wrB1, regKE1, regSh1, regRow1, rowOff0, rowCap0, first0 + tid + CLS_LANES);
 					__syncthreads();
 					if (stamp) { trace[5 * 32 + 1 + c] = clock64(); trace[7 * 32 + c] = L.colorStart[c + 1] - L.colorStart[c]; }
+				}
+				if (tailStart < numColors)
+				{
+					if (col0 >= tailStart && col0 < numColors)
+						for (u32 c = tailStart; c < numColors; ++c)
+						{
+							if (col0 == c) clSolveReg(lds, A, rdA0, wrA0, rdB0, wrB0, regKE0, regSh0, regRow0, rowOff0, rowCap0, first0 + tid);
+							__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+						}
+					if (col1 >= tailStart && col1 < numColors)
+						for (u32 c = tailStart; c < numColors; ++c)
+						{
+							if (col1 == c) clSolveReg(lds, A, rdA1, wrA1, rdB1, wrB1, regKE1, regSh1, regRow1, rowOff0, rowCap0, first0 + tid + CLS_LANES);
+							__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+						}
+					__syncthreads();
+					if (stamp) for (u32 c = tailStart; c < numColors; ++c) { trace[5 * 32 + 1 + c] = clock64(); trace[7 * 32 + c] = L.colorStart[c + 1] - L.colorStart[c]; }
 				}
 				for (u32 sp = serialStart; sp < taskCount; ++sp) // the serial tail (manifolds that found no colour below 64): one per step
 				{
@@ -1120,9 +1148,19 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 			{
 				const u32 col = (s2KE & 0x3FFu) >> 2; // 255 = no manifold
 				const u32 numColors = __builtin_amdgcn_readfirstlane(L.numColors), serialStart = __builtin_amdgcn_readfirstlane(L.serialStart), taskCount = __builtin_amdgcn_readfirstlane(L.count);
-				for (u32 c = 0; c < numColors; ++c)
+				for (u32 c = 0; c < tailStart1; ++c)
 				{
 					if (col == c) clSolveLds(lds, A, s2rdA, s2wrA, s2rdB, s2wrB, s2KE, s2Sh, s2rowBase, rowOff1, rowCap1, first1 + tid);
+					__syncthreads();
+				}
+				if (tailStart1 < numColors) // the trailing colours inside one wave, as in the register task
+				{
+					if (col >= tailStart1 && col < numColors)
+						for (u32 c = tailStart1; c < numColors; ++c)
+						{
+							if (col == c) clSolveLds(lds, A, s2rdA, s2wrA, s2rdB, s2wrB, s2KE, s2Sh, s2rowBase, rowOff1, rowCap1, first1 + tid);
+							__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+						}
 					__syncthreads();
 				}
 				for (u32 sp = serialStart; sp < taskCount; ++sp) // the serial tail: one manifold per step
