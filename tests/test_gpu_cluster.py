@@ -144,6 +144,29 @@ def test_cluster_follow_c3_full_size(mi, oracle):
     print("c3 full size:", {k: r[k] for k in ("num_pairs", "num_manifolds", "num_contacts", "vel_err", "pos_err")}, "tasks", st["clusterTasks"])
 
 
+def test_follow_c5_full_size_on_one_gpu(mi, oracle):
+    """BASELINE config 5's world (1M bodies, ~2.4M broadphase pairs, ~400k contacts) unsplit on ONE GPU: more manifolds than the
+    cluster sweep's workgroups can keep resident, so its build gives up, the step is redone with the launch-per-colour sweep and the
+    world backs off — the oracle follows whichever schedule the device reports: pair set exact, contact counts
+    exact, velocities within 1e-4.  (The 8-way partition of this config needs 8 GPUs; the partition itself is tested on c3_small.)"""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name("c5")
+    g = scene.instantiate(mi.World())
+    for _ in range(6):
+        g.step_internal(scene.dt)
+    o = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_CUSTOM))
+    o.write_state(g.transforms(1), g.velocities(), presort=True)
+    for i in range(2):
+        r = follow_step(g, o, scene.dt, 30)
+        assert r["pairs_equal"], "step %d: broadphase pair set differs (%d pairs)" % (i, r["num_pairs"])
+        assert r["counts_equal"], "step %d: contact counts differ" % i
+        assert r["vel_err"] <= 1e-4 * max(1.0, r["vel_scale"]), "step %d: velocity error %g" % (i, r["vel_err"])
+        assert r["pos_err"] <= 1e-4
+    st = g.stats()
+    print("c5 on one GPU:", {k: r[k] for k in ("num_pairs", "num_manifolds", "num_contacts", "vel_err", "pos_err")}, "recoveries", st["numFlowRecoveries"], "tasks", st["clusterTasks"])
+    assert r["num_pairs"] > 1500000 and np.isfinite(g.transforms(1)).all()
+
+
 @pytest.mark.parametrize("name, steps", [("c3_mid", 120), ("c4_small", 60)])
 def test_cluster_sweep_repeats_bit_identically(mi, name, steps):
     """The sweep's schedule is built with atomics (append cursors, hash insertion); its RESULTS must not depend on how they land:
