@@ -727,6 +727,7 @@ struct ClArgs
 	u32* counters; const ClTask* tasks; const u32* bodyList; const u32* bodyUsers; const u32* phaseMask; const u32* sharedSlot;
 	const u32* mKeySorted; const u32* mLocal; const u32* mExtra; const u32* mRank;
 	const float4* rowPlanes; const float4* rowShared; float2* rowLambda;
+	u32 predictDiv, pollSleep; // pacing of the hand-over polls (MI_CLUSTER_PREDICT_DIV / MI_CLUSTER_POLL_SLEEP)
 	float4* vel; u64* flow; u64* trace; // trace: developer timeline (mi_debug_flow_trace), normally null
 	size_t rowCap; u32 nb, flowBytes, epoch, itBegin, itEnd, ldsFloat4s;
 	// joints run by the sweep (null / 0 when the world has none or they keep their own launches): per phase-0 task the class offsets
@@ -1030,7 +1031,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 			{
 				if (k == 0 && lastWait > 64u && it > A.itBegin + 1u)
 				{
-					u64 until = lastPublish + (u64)(lastWait - lastWait / 4u);
+					u64 until = lastPublish + (u64)(lastWait - lastWait / A.predictDiv);
 					while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
 				}
 				const u32 rel = it - A.itBegin;
@@ -1074,7 +1075,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 						{
 							if (++spins > CL_SPIN_LIMIT) { atomicOr(status, 1u); sAbort = 1u; break; }
 							if ((spins & 63u) == 0u && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { sAbort = 1u; break; }
-							__builtin_amdgcn_s_sleep(1);
+							if (A.pollSleep == 1u) __builtin_amdgcn_s_sleep(1); else if (A.pollSleep >= 2u) __builtin_amdgcn_s_sleep(4);
 						}
 					}
 				}
@@ -1377,7 +1378,7 @@ void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd)
 	ClArgs A;
 	A.counters = w.dCounters.p; A.tasks = (const ClTask*)w.clTasks.p; A.bodyList = w.clBodyList.p; A.bodyUsers = w.clBodyUsers.p; A.phaseMask = w.clPhaseMask.p; A.sharedSlot = w.clSharedSlot.p;
 	A.mKeySorted = w.mKeySorted.p; A.mLocal = w.clLocal.p; A.mExtra = w.clExtra.p; A.mRank = w.clRankInfo.p;
-	A.rowPlanes = w.rowPlanes.p; A.rowShared = w.rowShared.p; A.rowLambda = w.rowLambda.p; A.vel = w.vel.p; A.flow = w.flow.p; A.trace = w.flowTrace.p;
+	A.rowPlanes = w.rowPlanes.p; A.rowShared = w.rowShared.p; A.rowLambda = w.rowLambda.p; A.vel = w.vel.p; A.flow = w.flow.p; A.trace = w.flowTrace.p; A.predictDiv = w.clusterPredictDiv; A.pollSleep = w.clusterPollSleep;
 	A.rowCap = w.rowCap; A.nb = w.nb; A.flowBytes = (u32)(words * sizeof(u64)); A.epoch = w.flowEpoch << 16; A.itBegin = itBegin; A.itEnd = itEnd;
 	A.ldsFloat4s = w.clusterLdsBytes / 16u;
 	const bool withJoints = cluster_solves_joints(w);

@@ -177,7 +177,7 @@ struct World
 	bool validate = false;                // MI_PHYSICS_VALIDATE=1 / mi_enable_validation: NaN / Inf guard after every stage (the reference's VALIDATE macros, physics.cpp:807-926)
 	bool useCluster = true;               // MI_PHYSICS_NO_CLUSTER=1: launch-per-colour sweep only
 	bool lastStepCluster = false, backupVelocities = false;
-	u32 clusterBlocksLimit = 0, clusterFailStreak = 0, clusterParts = 3, clusterTaskWeight = 64u * 1200u, clusterTaskWeightLater = 64u * 560u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
+	u32 clusterPredictDiv = 4, clusterPollSleep = 1, clusterBlocksLimit = 0, clusterFailStreak = 0, clusterParts = 3, clusterTaskWeight = 64u * 1200u, clusterTaskWeightLater = 64u * 560u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
 	bool clusterPartsFixed = false;       // MI_CLUSTER_PARTS given: no adaptation
 	bool clusterSortDue = true; u32 clusterSortAge = 0, clusterSortInterval = 8, clusterSortBodies = 0; // body order along the curves: refreshed every few steps (MI_CLUSTER_SORT_INTERVAL)
 	u32 clusterLdsBytes = 0, clusterBlocks = 0, clusterCooldown = 0;

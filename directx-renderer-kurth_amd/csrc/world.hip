@@ -58,6 +58,8 @@ World::World(int dev) : device(dev)
 	if (const char* e = getenv("MI_CLUSTER_PARTS")) { clusterParts = std::min<u32>(CL_MAX_PARTS, std::max(1, atoi(e))); clusterPartsFixed = true; }
 	if (const char* e = getenv("MI_CLUSTER_SORT_INTERVAL")) clusterSortInterval = (u32)std::max(1, atoi(e));
 	if (const char* e = getenv("MI_CLUSTER_TASK")) { clusterTaskWeight = 64u * (u32)std::max(16, atoi(e)); clusterTaskWeightLater = std::min(clusterTaskWeight, 64u * 560u); }  // manifolds per task
+	if (const char* e = getenv("MI_CLUSTER_PREDICT_DIV")) clusterPredictDiv = (u32)std::max(2, atoi(e));
+	if (const char* e = getenv("MI_CLUSTER_POLL_SLEEP")) clusterPollSleep = (u32)std::max(0, atoi(e));
 	if (const char* e = getenv("MI_CLUSTER_BLOCKS")) clusterBlocksLimit = (u32)std::max(1, atoi(e));
 	if (const char* e = getenv("MI_CLUSTER_TASK_LATER")) clusterTaskWeightLater = 64u * (u32)std::max(16, atoi(e)); // ... of the phases after the first
 	if (const char* e = getenv("MI_CLUSTER_SHIFT")) { int a = 0, b = 0, c = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) for (u32 p = 1; p < CL_MAX_PARTS; ++p) { clusterShift[p][0] = (u32)a * p; clusterShift[p][1] = (u32)b * p; clusterShift[p][2] = (u32)c * p; } }
