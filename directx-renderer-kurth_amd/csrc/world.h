@@ -238,7 +238,7 @@ struct World
 		u32 gridBlocks[MI_MAX_COLORS] = {};
 	} solveGraph;
 	u32 jointVersion = 0; u64 bufferVersion = 0;
-	bool useGraph = true;
+	bool useGraph = false;
 
 	World(int dev);
 	~World();

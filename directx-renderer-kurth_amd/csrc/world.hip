@@ -47,7 +47,10 @@ World::World(int dev) : device(dev)
 	if (dCounters.p) MI_CHECK(hipMemsetAsync(dCounters.p, 0, CTR_WORDS * sizeof(u32), stream));
 	stageEvents.resize(STAGE_RING * 6);
 	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
-	useGraph = getenv("MI_PHYSICS_NO_GRAPH") == nullptr; // rocprofv3's kernel trace needs plain launches
+	// The launch-per-colour sweep (the fallback solver) as plain launches: a hipGraph of its ~600 kernel nodes has to be re-instantiated
+	// whenever the number of colours changes (58 times in 260 steps of config 3, tens of ms each: 25 ms/step against 3 ms/step).
+	// MI_PHYSICS_GRAPH=1 replays it as a graph (pays off only where the colour count is stable: small resting scenes).
+	useGraph = getenv("MI_PHYSICS_GRAPH") != nullptr && getenv("MI_PHYSICS_NO_GRAPH") == nullptr;
 	validate = getenv("MI_PHYSICS_VALIDATE") != nullptr;
 	useCluster = getenv("MI_PHYSICS_NO_CLUSTER") == nullptr;
 	useClusterJoints = getenv("MI_CLUSTER_NO_JOINTS") == nullptr; // LDS cluster contact sweep (one launch) vs global colouring + one launch per colour
@@ -540,13 +543,24 @@ static void runSolverSweep(World& w, u32 iters, u32 numColors)
 // Global colouring + rows + the launch sweep: the whole solver stage of a step on the fallback path.
 static void solveWithLaunchSweep(World& w, u32 numPairs, float dt, u32 iters)
 {
-	launch_coloring(w, numPairs);
-	launch_contact_init(w, numPairs, dt);
-	launch_joint_init(w, dt);
 	u32 numColors = 0;
 	if (numPairs)
 	{
-		readCounters(w);                                   // sync #2: colour boundaries of the contact schedule
+		const size_t nb1 = (size_t)w.nb + 1;
+		for (u32 attempt = 0; ; ++attempt)
+		{
+			launch_coloring(w, numPairs);
+			readCounters(w);                               // sync #2: colour boundaries of the contact schedule
+			// Manifolds the round budget left uncoloured sit in a serial bucket that ONE wave sweeps (correct, and fine for a handful).
+			// A colouring from scratch on a short budget can leave thousands there (measured: 4 ms per iteration on config 3): colour
+			// again from scratch with four times the rounds instead (a round is one 5 us launch).
+			if (w.hCounters[CTR_OVERFLOW] <= 64u || attempt >= 3u) break;
+			w.coloringRounds = std::min(1024u, std::max(w.coloringRounds, 16u) * 4u);
+			w.forceFullColoring = true;
+			MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_NUM_ACTIVE, 0, 2 * sizeof(u32), w.stream)); // active-list cursor + contact count: the list is rebuilt
+			MI_CHECK(hipMemsetAsync(w.bodyMask.p, 0, sizeof(u64) * nb1, w.stream));
+			MI_CHECK(hipMemsetAsync(w.claim.p, 0xFF, sizeof(u64) * 2 * nb1, w.stream));
+		}
 		numColors = w.hCounters[CTR_NUM_COLORS];
 		w.lastNumManifolds = w.hCounters[CTR_NUM_MANIFOLDS];
 		// adaptive colouring budget: last round that made progress + margin; grow quickly on overflow
@@ -554,6 +568,8 @@ static void solveWithLaunchSweep(World& w, u32 numPairs, float dt, u32 iters)
 		w.coloringRounds = w.hCounters[CTR_OVERFLOW] ? std::min(1024u, w.coloringRounds * 2) : std::max(12u, lastUseful + 6);
 	}
 	else { memset(w.hCounters + CTR_KEY_START, 0, sizeof(u32) * (MI_NUM_SCHEDULE_KEYS + 1)); w.hCounters[CTR_NUM_MANIFOLDS] = 0; w.hCounters[CTR_NUM_VALID] = 0; w.lastNumManifolds = 0; }
+	launch_contact_init(w, numPairs, dt);
+	launch_joint_init(w, dt);
 	runSolverSweep(w, iters, numColors);
 }
 
