@@ -93,3 +93,26 @@ def test_validation_guard_reports_non_finite_state(mi):
     with pytest.raises(mi.PhysicsError, match="non-finite"):
         w.step_internal(scene.dt)
         w.stats()
+
+
+def test_spawn_and_poke_in_the_same_frame(mi, oracle):
+    """A body added to a world that has already stepped, and in the same frame a velocity set and a force applied on OLD bodies
+    (the host mirror must stay authoritative until the next upload: the state download that precedes it must not overwrite the
+    pokes).  Device and oracle do the same calls and keep matching."""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name("c3_small")
+    g, o = _worlds(mi, oracle, scene)
+    for _ in range(20):
+        follow_step(g, o, scene.dt, 30, {})
+    for frame in range(3):
+        for w in (g, o):
+            b = w.add_body((0.3 * frame, 30.0 + frame, -0.2 * frame))
+            w.add_collider(b, 0, (0.0, 0.0, 0.0, 0.4), (0.1, 0.5, 2.0))     # a sphere at the body's origin
+            w.set_velocity(11 + frame, (1.5, 2.0, -0.5), (0.0, 3.0, 0.0))
+            w.apply_force_torque(100 + frame, (40.0, 300.0, -10.0), (0.0, 2.0, 0.0))
+        for i in range(4):
+            r = follow_step(g, o, scene.dt, 30, {})
+            assert r["pairs_equal"] and r["counts_equal"], (frame, i)
+            assert r["vel_err"] <= 1e-4 * max(1.0, r["vel_scale"]) and r["pos_err"] <= 1e-4, (frame, i, r["vel_err"], r["pos_err"])
+    assert g.num_bodies == scene.num_bodies + 3
+    assert g.velocities()[11, 1] != 0.0
