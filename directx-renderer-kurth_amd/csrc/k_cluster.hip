@@ -357,11 +357,19 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 	u32* jHist = hist + 264;                            // [CL_MAX_JOINT_CLASSES + 1] joints per (type, colour) class, then cursors
 	__shared__ u32 sNumShared, sNumPrivate, sMaxColor, sScan[16], sSharedBase;
 	const u32 tid = threadIdx.x;
-	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
 	// developer timeline (mi_debug_flow_trace): row 14 of the task's 16 rows = core-clock stamps of the stages below, [15] = colouring rounds
 #define CL_STAMP(I_) if (trace && tid == 0 && key < CL_MAX_TASKS) trace[((size_t)key * 16u + 14u) * 32u + (I_)] = clock64();
 
-	for (u32 key = blockIdx.x; key < totalKeys; key += gridDim.x)
+	// Task t of phase p is built by workgroup (tasks of the earlier phases + t) % G — the rotation the solve launch uses — so that
+	// the later phases' tasks go to the workgroups the first phase left idle first, and nobody builds more than
+	// ceil(tasks / G) + 1 of them (by key order workgroup 0 built one task of EVERY phase: 4 x 35 us on the kernel's critical path).
+	u32 phaseOffset = 0;
+	for (u32 ph = 0; ph < CL_MAX_PHASES; ++ph)
+	{
+	const u32 tasksInPhase = counters[CTR_CL_NUM_TASKS + ph];
+	const u32 tFirst = (blockIdx.x + gridDim.x - (phaseOffset % gridDim.x)) % gridDim.x;
+	phaseOffset += tasksInPhase;
+	for (u32 key = ph * CL_MAX_TASKS + tFirst; key < ph * CL_MAX_TASKS + min(tasksInPhase, CL_MAX_TASKS); key += gridDim.x)
 	{
 		u32 first = taskStart[key * CL_SUBCOUNTERS], n = taskStart[(key + 1u) * CL_SUBCOUNTERS] - first;
 		ClTask* T = tasks + key;
@@ -685,6 +693,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 		}
 		__syncthreads();
 		CL_STAMP(7)
+	}
 	}
 #undef CL_STAMP
 }
