@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, cons
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i > nb) return;
 	if (bodyMask) { bodyMask[i] = 0ull; claim[i] = ~0ull; claim[(size_t)nb + i] = ~0ull; } // per-body state of the colouring that follows (saves three fill launches)
-	// velBackup: the pre-solve velocities, kept in case the dataflow sweep has to be redone (World::recoverFlow); written here, where
+	// velBackup: the pre-solve velocities, kept in case the cluster sweep has to be redone (World::recoverFlow); written here, where
 	// every body's velocity passes through registers anyway, instead of by a copy of the whole array afterwards
 	if (i < nb && !simMask[i]) { if (velBackup) { velBackup[2 * i] = vel[2 * i]; velBackup[2 * i + 1] = vel[2 * i + 1]; } return; }
 	if (i == nb) // static dummy (physics.cpp:1279)
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256) k_integrate_velocities(u32 nb, float dt, 
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= nb || !simMask[i]) return;
-	if (*flowStatus) return; // the dataflow sweep gave up: velocities are invalid, the host redoes the solve and this integration (World::recoverFlow)
+	if (*flowStatus) return; // the cluster sweep gave up: velocities are invalid, the host redoes the solve and this integration (World::recoverFlow)
 	Q4 grot = q4f4(pose[2 * i + 1]);
 	V3 gpos = v3f4(cog[i]);
 	V3 v = v3f4(vel[2 * i]), wv = v3f4(vel[2 * i + 1]);

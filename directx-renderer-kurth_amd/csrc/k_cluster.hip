@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 		}
 		__syncthreads();
 		CL_STAMP(6)
-		// 6. rank of every manifold among the users of each of its bodies, in position order (the dataflow sweep's turn numbers).
+		// 6. rank of every manifold among the users of each of its bodies, in position order (the hand-over turn numbers).
 		// Coloured manifolds: a colour occurs once per body, so the rank is the number of lower colours in the body's mask.  The serial
 		// tail (no colour left below 64: bodies with more than 64 users in this task) is walked by one lane in position order.
 		u32* inv = hKey;   // serial manifolds by position (the hash is no longer needed)

@@ -72,13 +72,13 @@ enum
 	CTR_NUM_CONTACTS = 10,  // sum of contact counts over the active manifolds
 	CTR_PAIR_OVERFLOW = 11, // some collider has more broadphase partners than its slab holds
 	CTR_FIRST_INACTIVE = 12,// sorted position of the first collider whose body is simulated by another GPU
-	CTR_FLOW_STATUS = 13,   // dataflow sweep: non-zero = a lane gave up waiting (result invalid); cleared by k_color_offsets
+	CTR_FLOW_STATUS = 13,   // cluster sweep: non-zero = the launch could not run or a lane gave up waiting (result invalid): the host redoes the step
 	CTR_EPA_COUNT_HULL = 15,// GJK hits among the hull pairs (their EPA work list grows from the end of epaList)
-	CTR_FLOW_PROBES = 14,   // dataflow sweep: number of record polls of the step (must directly follow CTR_FLOW_STATUS)
+	CTR_FLOW_PROBES = 14,   // unused (kept: the statistics layout has the word)
 	CTR_BUCKET_START = 16,  // 65 words: first slot of narrowphase bucket key b (tA*6+tB); [64] unused
 	CTR_KEY_START = 96,     // (MI_MAX_COLORS+1)*4 + 1 words: first schedule slot of key colour*4 + (4-count); last = numManifolds
 	CTR_COLOR_BARRIER = 360,// 4 words: grid barrier of the fused colouring kernel (arrivals, 3 x manifolds left)
-	CTR_FLOW_CENSUS = 368,  // 16 words: workgroups of the running dataflow launch per XCD [0..7], registered [8], finished [9]
+	CTR_FLOW_CENSUS = 368,  // 16 words, unused (round 1's dataflow launch counted its workgroups per XCD here)
 	CTR_REGION_START = 384, // 9 words: first position in flowOrder of XCD region r; [8] = numManifolds
 	CTR_REGION_CUTS = 400,  // 7 floats: region r holds bodies with cuts[r-1] <= x < cuts[r]
 	CTR_REGION_RANGE = 408, // 2 floats: [lo, hi] of the histogram that produces the next cuts
@@ -225,7 +225,6 @@ struct World
 	void harvestTiming();
 	// Counts of the steps since the last mi_get_stats (the host learns a step's counts at its next synchronisation)
 	double sumContacts = 0, sumManifolds = 0, sumColors = 0, sumPairs = 0, sumProbes = 0; u32 sumSteps = 0, countedStep = 0, prevNumPairs = 0;
-	bool useSync2 = false;                // MI_PHYSICS_SYNC2=1: read the colour table back every step even when the dataflow sweep does not need it
 	void countPreviousStep(); void refreshCounters();
 
 	// The N-iteration solver sweep (joint colours + contact colours per iteration) replayed as one hipGraph.  Launch arguments are
@@ -270,7 +269,6 @@ void launch_active_list(World& w, u32 numPairs);           // manifolds with con
 void launch_cluster_build(World& w, u32 numPairs);         // body order, tasks, local colouring, final slot order (k_cluster.hip)
 void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd);
 bool cluster_solves_joints(const World& w);                // the cluster sweep of this step runs the joints too (one launch for all iterations)
-void launch_flow_regions(World& w, u32 numManifolds);       // region-major slot order for the XCD-local dataflow sweep
 u32 flow_num_regions(const World& w);
 void flow_choose_regions(World& w);
 void launch_integrate_velocities(World& w, float dt);

@@ -268,8 +268,9 @@ uint32_t mi_debug_num_colors(mi_world* w);
 int mi_debug_read_schedule(mi_world* w, uint32_t* outManifoldSlots, uint32_t* outColorStart /* numColors+1 */);
 int mi_debug_read_joint_order(mi_world* w, uint32_t type, uint32_t* outJointIds);
 int mi_debug_read_body_state(mi_world* w, float* outCog4, float* outInvInertia12, uint32_t nPlusOne); /* rbGlobal: {cog.xyz, invMass}, 3 x float4 columns */
-/* Developer timeline of the dataflow contact sweep: enable != 0 allocates it (32 x u64 per schedule slot), out (may be NULL) receives the
- * wall-clock stamp (10 ns ticks) at which each slot's manifold finished iteration i of the last step. */
+/* Developer timeline of the cluster contact sweep: enable != 0 allocates it (16 rows of 32 u64 per workgroup of the solve launch), out (may be
+ * NULL) receives numSlots rows: per task and iteration the wall-clock stamps (10 ns ticks) "shared bodies acquired" / "colours done", the cost of
+ * every colour step of iteration 10, and the stages of the task's colouring (csrc/k_cluster.hip documents the rows; tests/cluster_timeline.py prints them). */
 int mi_debug_flow_trace(mi_world* w, int enable, unsigned long long* out, uint32_t numSlots);
 
 #ifdef __cplusplus
