@@ -140,10 +140,12 @@ class SlabWorld:
     moves them (RCCL over xGMI, enqueued on the world's own stream: the host does not wait for it), two small kernels apply what
     arrived.  No host synchronisation is added to the step's own one.  `comm_on_cpu` (gloo rehearsals of several ranks on one GPU)
     stages the messages through host memory instead, which does synchronise.
-    The slabs are cut along the axis of largest variance of the initial positions, at body-count quantiles; the cuts stay where
-    they are (no re-cut: a pile that flows far from its start unbalances the slabs, it does not break them)."""
+    The slabs are cut along the axis of largest variance of the initial positions, at body-count quantiles, and re-cut every
+    `recut_interval` steps at the quantiles of the CURRENT positions (a pile that flows away from its start would otherwise
+    unbalance the slabs): every rank then needs every body's state, which is assembled with two all-reduces of the owners'
+    contributions — the one place where the slab runner uses a collective, once per few hundred steps."""
 
-    def __init__(self, scene, device, rank, world_size, axis=None, margin=3.0, comm_on_cpu=False, capacity=None):
+    def __init__(self, scene, device, rank, world_size, axis=None, margin=3.0, comm_on_cpu=False, capacity=None, recut_interval=240):
         import directx_renderer_kurth_amd as mi
         self.rank, self.world_size, self.scene, self.comm_on_cpu = rank, world_size, scene, comm_on_cpu
         self.dev = torch.device("cuda", device)
@@ -156,6 +158,7 @@ class SlabWorld:
         hi = cuts[rank] if rank < world_size - 1 else float("inf")
         self.left = rank - 1 if rank > 0 else None
         self.right = rank + 1 if rank < world_size - 1 else None
+        self.margin, self.cuts, self.recut_interval, self.steps, self.recuts = margin, cuts, int(recut_interval), 0, 0
         self.world.slab_configure(rank, world_size, self.axis, lo, hi, margin)
         self.capacity = int(capacity or max(4096, n // max(2, world_size)))
         nbytes = self.world.slab_message_bytes(self.capacity)
@@ -193,9 +196,23 @@ class SlabWorld:
             self.bytes_sent += sum(t.numel() for t in self.out.values())
             w.slab_unpack(self._ptr(self.inc, self.left), self._ptr(self.inc, self.right), self.capacity)
 
+    def recut(self):
+        """New cuts at the body-count quantiles of the current positions.  Collective: every rank ends up with every body's current
+        state (owners' contributions summed), writes it into its world and re-classifies ownership from it."""
+        t, v = self.transforms(1), self.velocities()
+        self.world.write_state(t, v)
+        self.cuts = quantile_cuts(t[:, self.axis].astype(np.float64), self.world_size)
+        lo = self.cuts[self.rank - 1] if self.rank > 0 else -float("inf")
+        hi = self.cuts[self.rank] if self.rank < self.world_size - 1 else float("inf")
+        self.world.slab_configure(self.rank, self.world_size, self.axis, lo, hi, self.margin)
+        self.recuts += 1
+
     def step_internal(self, dt, iterations=30):
+        if self.world_size > 1 and self.recut_interval and self.steps and self.steps % self.recut_interval == 0:
+            self.recut()
         self.exchange()
         self.world.step_internal(dt, iterations)
+        self.steps += 1
 
     def dropped(self):
         """Bodies that did not fit this rank's last outgoing messages (must be 0: raise `capacity`)."""

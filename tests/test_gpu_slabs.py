@@ -92,7 +92,7 @@ def _worker(rank, world_size, port, steps, out_dir):
     torch.cuda.set_device(0)
     from directx_renderer_kurth_amd import scenes, parallel
     scene = scenes.by_name("c3_small")
-    sw = parallel.SlabWorld(scene, device=0, rank=rank, world_size=world_size, margin=3.5, comm_on_cpu=True)
+    sw = parallel.SlabWorld(scene, device=0, rank=rank, world_size=world_size, margin=3.5, comm_on_cpu=True, recut_interval=15)   # two re-cuts inside the run
     for _ in range(steps):
         sw.step_internal(scene.dt)
         tot = torch.as_tensor(sw.owned_mask().astype(np.int32)); dist.all_reduce(tot)
@@ -102,7 +102,7 @@ def _worker(rank, world_size, port, steps, out_dir):
     codes = sw.world.slab_codes()
     if rank == 0:
         np.save(os.path.join(out_dir, "t.npy"), t); np.save(os.path.join(out_dir, "v.npy"), v)
-        np.save(os.path.join(out_dir, "stats.npy"), np.array([sw.bytes_sent, int((codes != parallel.INACTIVE).sum()), sw.host_syncs, sw.axis]))
+        np.save(os.path.join(out_dir, "stats.npy"), np.array([sw.bytes_sent, int((codes != parallel.INACTIVE).sum()), sw.host_syncs, sw.axis, sw.recuts]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -118,8 +118,9 @@ def test_two_slabs_match_single_world(tmp_path, mi):
     w.close()
     mp.spawn(_worker, args=(2, _free_port(), steps, str(tmp_path)), nprocs=2, join=True)
     t = np.load(os.path.join(str(tmp_path), "t.npy")); v = np.load(os.path.join(str(tmp_path), "v.npy"))
-    sent, active, syncs, axis = np.load(os.path.join(str(tmp_path), "stats.npy"))
+    sent, active, syncs, axis, recuts = np.load(os.path.join(str(tmp_path), "stats.npy"))
     assert np.isfinite(t).all() and sent > 0 and active < scene.num_bodies
+    assert recuts == 2                            # steps 15 and 30: ownership re-derived from the all-reduced state, the partition asserts above held through them
     assert syncs == steps                         # the rehearsal path stages through the host once per step; the RCCL path adds none
     x0 = np.array([b[0] for b in scene.bodies], np.float64)[:, int(axis)]
     cut = parallel.quantile_cuts(x0, 2)[0]
