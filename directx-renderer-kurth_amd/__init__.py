@@ -77,6 +77,7 @@ EXPORTED_SYMBOLS = [
     "mi_get_stats", "mi_enable_validation", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_slab_configure", "mi_slab_message_bytes", "mi_slab_pack", "mi_slab_unpack", "mi_slab_read_codes", "mi_debug_num_pairs", "mi_debug_read_pairs",
     "mi_debug_read_world_colliders", "mi_debug_num_manifold_slots", "mi_debug_read_manifolds", "mi_debug_num_colors", "mi_debug_read_schedule",
     "mi_debug_read_joint_order", "mi_debug_read_body_state", "mi_debug_flow_trace",
+    "mi_debug_set_replay", "mi_debug_num_replay_batches", "mi_debug_read_replay_batches",
 ]
 
 
@@ -472,6 +473,18 @@ class World:
         out = np.zeros((max(1, num_slots), 32), np.uint64)
         self._check(self.lib.mi_debug_flow_trace(self.w, int(enable), _p(out) if num_slots else None, C.c_uint32(num_slots)))
         return out
+
+    def set_replay(self, on=True):
+        """Solve contacts in the REFERENCE's own order from now on (its greedy 8-wide batch schedule, batch after batch): parity facility."""
+        self._check(self.lib.mi_debug_set_replay(self.w, int(on)))
+
+    def replay_batches(self):
+        """The last step's batches [numBatches, 8]: schedule position | contact << 28, 0xFFFFFFFF = empty lane."""
+        self.lib.mi_debug_num_replay_batches.restype = C.c_uint32
+        n = int(self.lib.mi_debug_num_replay_batches(self.w))
+        out = np.zeros((max(n, 1), 8), np.uint32)
+        self._check(self.lib.mi_debug_read_replay_batches(self.w, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out[:n]
 
     def body_state(self):
         n = self.num_bodies + 1

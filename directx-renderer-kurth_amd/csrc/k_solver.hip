@@ -394,6 +394,43 @@ __global__ void __launch_bounds__(1024) k_solve_tail(u32 firstColor, u32 numColo
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Replay of the REFERENCE's own contact order (debug facility, mi_debug_set_replay): the host runs the reference's greedy batch
+// scheduler over this step's contacts (World::scheduleReferenceBatches, constraints.cpp:51-184) and this kernel sweeps the batches
+// one after the other — the order solveCollisionVelocityConstraintsSIMD executes them in (constraints.cpp:3618-3709) — with the
+// lanes of a batch (disjoint bodies) side by side.  Contact-granular: entry = schedule position | contact index << 28.
+// One workgroup, a barrier between batches (same CU, same L1: the next batch sees this batch's velocity writes, as in k_solve_tail).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_solve_replay(u32 numBatches, const u32* __restrict__ entries, u32 nb, size_t rowCap, const float4* __restrict__ rowPlanes,
+	const float4* __restrict__ rowShared, float2* __restrict__ rowLambda, const uint4* __restrict__ rowIds, float4* __restrict__ vel)
+{
+	for (u32 bi = 0; bi < numBatches; ++bi)
+	{
+		u32 e = threadIdx.x < MI_REPLAY_WIDTH ? entries[bi * MI_REPLAY_WIDTH + threadIdx.x] : 0xFFFFFFFFu;
+		if (e != 0xFFFFFFFFu)
+		{
+			u32 s = e & 0x0FFFFFFFu, k = e >> 28;
+			uint4 ids = rowIds[s];
+			float4 sh = rowShared[s];
+			ContactRow r;
+			loadRow(r, k, s, rowCap, rowPlanes, rowLambda);
+			u32 a = ids.x, b = ids.y;
+			float4 la = vel[2 * a], aa = vel[2 * a + 1], lb = vel[2 * b], ab = vel[2 * b + 1];
+			V3 vA = v3f4(la), wA = v3f4(aa), vB = v3f4(lb), wB = v3f4(ab);
+			solveRow(r, v3(sh.x, sh.y, sh.z), sh.w, la.w, lb.w, vA, wA, vB, wB);
+			rowLambda[(size_t)k * rowCap + s] = r.lam;
+			if (a < nb) { vel[2 * a] = make_float4(vA.x, vA.y, vA.z, la.w); vel[2 * a + 1] = make_float4(wA.x, wA.y, wA.z, 0.f); }
+			if (b < nb) { vel[2 * b] = make_float4(vB.x, vB.y, vB.z, lb.w); vel[2 * b + 1] = make_float4(wB.x, wB.y, wB.z, 0.f); }
+		}
+		__syncthreads();
+	}
+}
+void launch_solve_replay(World& w, u32 numBatches)
+{
+	if (!numBatches) return;
+	hipLaunchKernelGGL(k_solve_replay, dim3(1), dim3(64), 0, w.stream, numBatches, w.replayEntries.p, w.nb, w.rowCap, w.rowPlanes.p, w.rowShared.p, w.rowLambda.p, w.rowIds.p, w.vel.p);
+}
+
 // One Gauss-Seidel iteration over all contact colours; colour c < firstTail is launched with gridBlocks[c] blocks (0 = skip),
 // colours [firstTail, numColors) go to the single-workgroup tail kernel.
 void launch_solve_contacts_iteration(World& w, const u32* gridBlocks, u32 numColors, u32 firstTail, bool serialBucket)

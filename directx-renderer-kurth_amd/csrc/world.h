@@ -97,6 +97,7 @@ enum
 	CTR_WORDS = 512,
 };
 // Cluster sweep (k_cluster.hip): up to CL_MAX_PARTS partition phases + the rest phase; task key = phase * CL_MAX_TASKS + task.
+#define MI_REPLAY_WIDTH 8u // lanes of the reference's SIMD batches (constraints.cpp: CONSTRAINT_SIMD_WIDTH with AVX)
 #define CL_MAX_PARTS 4u
 #define CL_MAX_PHASES (CL_MAX_PARTS + 1u)
 #define CL_MAX_TASKS 512u
@@ -175,6 +176,9 @@ struct World
 	DevBuf<u64> flow;                     // cluster sweep: 32-byte hand-over record per (phase, shared body): two tagged 16-byte halves
 	// cluster sweep (k_cluster.hip)
 	bool validate = false;                // MI_PHYSICS_VALIDATE=1 / mi_enable_validation: NaN / Inf guard after every stage (the reference's VALIDATE macros, physics.cpp:807-926)
+	// replay of the reference's batch order (mi_debug_set_replay / MI_PHYSICS_REPLAY=1; a test facility: the whole contact sweep is ONE workgroup)
+	bool replayReferenceOrder = false; DevBuf<u32> replayEntries; std::vector<u32> replayHost; u32 replayBatches = 0;
+	u32 scheduleReferenceBatches(const std::vector<uint4>& ids, u32 numPositions);
 	bool useCluster = true;               // MI_PHYSICS_NO_CLUSTER=1: launch-per-colour sweep only
 	bool lastStepCluster = false, backupVelocities = false;
 	u32 clusterPredictDiv = 4, clusterPollSleep = 1, clusterBlocksLimit = 0, clusterFailStreak = 0, clusterParts = 3, clusterTaskWeight = 64u * 1200u, clusterTaskWeightLater = 64u * 560u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
@@ -263,6 +267,7 @@ void launch_trigger_events(World& w);                      // leave events + tab
 void launch_collision_events(World& w, u32 numPairs);      // begin / end events of this step's manifolds (after the force integration)
 void launch_coloring(World& w, u32 numPairs);
 void launch_contact_init(World& w, u32 numPairs, float dt);
+void launch_solve_replay(World& w, u32 numBatches);
 void launch_solve_contacts_iteration(World& w, const u32* gridBlocks, u32 numColors, u32 firstTail, bool serialBucket);
 bool cluster_available(World& w);                          // sets up the cluster kernels' LDS budget once; false = this device cannot run them
 void launch_active_list(World& w, u32 numPairs);           // manifolds with contacts -> actIds (no colours)

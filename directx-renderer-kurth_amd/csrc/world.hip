@@ -61,6 +61,7 @@ World::World(int dev) : device(dev)
 	if (const char* e = getenv("MI_CLUSTER_PARTS")) { clusterParts = std::min<u32>(CL_MAX_PARTS, std::max(1, atoi(e))); clusterPartsFixed = true; }
 	if (const char* e = getenv("MI_CLUSTER_SORT_INTERVAL")) clusterSortInterval = (u32)std::max(1, atoi(e));
 	if (const char* e = getenv("MI_CLUSTER_TASK")) { clusterTaskWeight = 64u * (u32)std::max(16, atoi(e)); clusterTaskWeightLater = std::min(clusterTaskWeight, 64u * 560u); }  // manifolds per task
+	if (getenv("MI_PHYSICS_REPLAY")) replayReferenceOrder = true;
 	if (const char* e = getenv("MI_CLUSTER_PREDICT_DIV")) clusterPredictDiv = (u32)std::max(2, atoi(e));
 	if (const char* e = getenv("MI_CLUSTER_POLL_SLEEP")) clusterPollSleep = (u32)std::max(0, atoi(e));
 	if (const char* e = getenv("MI_CLUSTER_BLOCKS")) clusterBlocksLimit = (u32)std::max(1, atoi(e));
@@ -540,6 +541,53 @@ static void runSolverSweep(World& w, u32 iters, u32 numColors)
 	if (g.exec) MI_CHECK(hipGraphLaunch(g.exec, w.stream));
 }
 
+// The reference's greedy batch scheduler for W-wide SIMD solves (scheduleConstraintsSIMD, constraints.cpp:51-184), restated for the
+// replay facility: constraints are dealt round-robin to four buckets; inside its bucket a constraint goes to the first open batch
+// none of whose lanes shares a body with it (a static body conflicts with nothing: it is replaced by the constraint's other body
+// for the test), into that batch's lowest free lane; a batch that fills up is emitted at once, the partly filled ones follow bucket
+// by bucket at the end.  Contacts are enumerated the way the reference emits them: manifold by manifold in narrowphase order, a
+// manifold's contacts in order.  ids = the schedule's id quads {body a, body b, contacts, narrowphase slot} by schedule position.
+// Result: replayHost = entries (position | contact << 28, 0xFFFFFFFF = empty lane), MI_REPLAY_WIDTH per batch.
+u32 World::scheduleReferenceBatches(const std::vector<uint4>& ids, u32 numPositions)
+{
+	const u32 W = MI_REPLAY_WIDTH, NONE = 0xFFFFFFFFu, numBuckets = 4, dummy = nb;
+	std::vector<u32> bySlot(numPositions);
+	for (u32 i = 0; i < numPositions; ++i) bySlot[i] = i;
+	std::sort(bySlot.begin(), bySlot.end(), [&](u32 x, u32 y) { return ids[x].w < ids[y].w; });
+	struct Batch { u32 a[MI_REPLAY_WIDTH], b[MI_REPLAY_WIDTH], entry[MI_REPLAY_WIDTH]; };
+	auto emptyBatch = [&]() { Batch e; for (u32 l = 0; l < W; ++l) { e.a[l] = e.b[l] = NONE; e.entry[l] = NONE; } return e; };
+	std::vector<Batch> open[numBuckets];
+	u32 count[numBuckets] = { 0, 0, 0, 0 };
+	for (u32 q = 0; q < numBuckets; ++q) open[q].push_back(emptyBatch()); // the always-accepting batch behind the last open one
+	replayHost.clear();
+	auto emit = [&](const Batch& e) { for (u32 l = 0; l < W; ++l) replayHost.push_back(e.entry[l]); };
+	u32 index = 0;
+	for (u32 p : bySlot)
+		for (u32 k = 0; k < ids[p].z; ++k, ++index)
+		{
+			const u32 bodyA = ids[p].x, bodyB = ids[p].y;
+			const u32 testA = bodyA == dummy ? bodyB : bodyA, testB = bodyB == dummy ? bodyA : bodyB;
+			std::vector<Batch>& es = open[index % numBuckets];
+			u32 j = 0;
+			for (;; ++j)
+			{
+				const Batch& e = es[j];
+				bool conflict = false;
+				for (u32 l = 0; l < W && !conflict; ++l) conflict = e.a[l] == testA || e.b[l] == testA || e.a[l] == testB || e.b[l] == testB;
+				if (!conflict) break;
+			}
+			Batch& e = es[j];
+			u32 lane = 0;
+			while (!(e.a[lane] == NONE && e.b[lane] == NONE)) ++lane;
+			e.entry[lane] = p | (k << 28); e.a[lane] = bodyA; e.b[lane] = bodyB;
+			u32& c = count[index % numBuckets];
+			if (j == c) { ++c; if (es.size() <= c) es.push_back(emptyBatch()); else es[c] = emptyBatch(); }
+			else if (lane == W - 1) { Batch full = e; --c; es[j] = es[c]; emit(full); es[c] = emptyBatch(); }
+		}
+	for (u32 q = 0; q < numBuckets; ++q) for (u32 i = 0; i < count[q]; ++i) emit(open[q][i]);
+	return (u32)(replayHost.size() / W);
+}
+
 // Global colouring + rows + the launch sweep: the whole solver stage of a step on the fallback path.
 static void solveWithLaunchSweep(World& w, u32 numPairs, float dt, u32 iters)
 {
@@ -570,6 +618,18 @@ static void solveWithLaunchSweep(World& w, u32 numPairs, float dt, u32 iters)
 	else { memset(w.hCounters + CTR_KEY_START, 0, sizeof(u32) * (MI_NUM_SCHEDULE_KEYS + 1)); w.hCounters[CTR_NUM_MANIFOLDS] = 0; w.hCounters[CTR_NUM_VALID] = 0; w.lastNumManifolds = 0; }
 	launch_contact_init(w, numPairs, dt);
 	launch_joint_init(w, dt);
+	if (w.replayReferenceOrder) // the reference's batch order instead of the colour schedule (debug facility: one workgroup sweeps all contacts)
+	{
+		const u32 numPositions = numPairs ? w.hCounters[CTR_NUM_MANIFOLDS] : 0u;
+		std::vector<uint4> ids(numPositions);
+		if (numPositions) { MI_CHECK(hipMemcpyAsync(ids.data(), w.rowIds.p, sizeof(uint4) * numPositions, hipMemcpyDeviceToHost, w.stream)); MI_CHECK(hipStreamSynchronize(w.stream)); }
+		w.replayBatches = w.scheduleReferenceBatches(ids, numPositions);
+		w.replayEntries.ensure(std::max<size_t>(w.replayHost.size(), 1), w.stream);
+		if (w.lastError) return;
+		if (!w.replayHost.empty()) MI_CHECK(hipMemcpyAsync(w.replayEntries.p, w.replayHost.data(), sizeof(u32) * w.replayHost.size(), hipMemcpyHostToDevice, w.stream));
+		for (u32 it = 0; it < iters; ++it) { launch_joint_solve_iteration(w); launch_solve_replay(w, w.replayBatches); } // joints before contacts (constraints.cpp:3748-3772)
+		return;
+	}
 	runSolverSweep(w, iters, numColors);
 }
 
@@ -734,7 +794,7 @@ int World::stepInternal(float dt, u32 iters)
 	if (clusterCooldown) --clusterCooldown;
 	// Contact solver of this step: the LDS cluster sweep (one persistent launch, no host synchronisation: everything is sized on the
 	// device), or global colouring + one launch per colour when it is switched off, recovering, or cannot hold the turn counters.
-	const bool clusterStep = useCluster && !clusterCooldown && numPairs && iters && iters < 4096u && cluster_available(*this);
+	const bool clusterStep = useCluster && !replayReferenceOrder && !clusterCooldown && numPairs && iters && iters < 4096u && cluster_available(*this);
 	backupVelocities = clusterStep;                        // pre-solve velocities, in case the cluster sweep has to be redone (World::recoverFlow)
 	if (clusterStep) velBackup.ensure(2 * ((size_t)nb + 1), stream);
 	launch_integrate_forces(*this, dt);
@@ -2220,6 +2280,19 @@ int mi_debug_read_body_state(mi_world* world, float* outCog4, float* outInvInert
 	d2h(W, outCog4, W->cog.p, sizeof(float4) * n); d2h(W, outInvInertia12, W->invIw.p, sizeof(float4) * 3 * n);
 	return W->lastError;
 }
+/* Replay facility: on != 0 makes every following step solve its contacts in the REFERENCE's own order (its greedy 8-wide batch
+ * scheduler over the contacts in emission order, constraints.cpp:51-184, batches executed one after the other) instead of the
+ * device's schedule.  One workgroup sweeps everything: for parity tests on small worlds, not for speed. */
+int mi_debug_set_replay(mi_world* world, int on)
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	W->resolvePendingFlow();
+	W->replayReferenceOrder = on != 0;
+	W->forceFullColoring = true;
+	return MI_OK;
+}
+uint32_t mi_debug_num_replay_batches(mi_world* world) { CHECK_WORLD(0); return W->replayBatches; }
+int mi_debug_read_replay_batches(mi_world* world, uint32_t* outEntries) { CHECK_WORLD(MI_ERR_INVALID_ARGUMENT); if (!W->replayHost.empty()) memcpy(outEntries, W->replayHost.data(), sizeof(u32) * W->replayHost.size()); return MI_OK; }
 /* Developer timeline of the cluster sweep: enable (allocates 16 rows of 32 stamps per workgroup of the solve launch), step, then read
  * numSlots rows of 32 u64 (k_cl_solve documents the rows; wall-clock stamps are 10 ns ticks). */
 int mi_debug_flow_trace(mi_world* world, int enable, unsigned long long* out, uint32_t numSlots)

@@ -268,6 +268,14 @@ uint32_t mi_debug_num_colors(mi_world* w);
 int mi_debug_read_schedule(mi_world* w, uint32_t* outManifoldSlots, uint32_t* outColorStart /* numColors+1 */);
 int mi_debug_read_joint_order(mi_world* w, uint32_t type, uint32_t* outJointIds);
 int mi_debug_read_body_state(mi_world* w, float* outCog4, float* outInvInertia12, uint32_t nPlusOne); /* rbGlobal: {cog.xyz, invMass}, 3 x float4 columns */
+/* Replay of the reference's own Gauss-Seidel order (SURVEY section 7 / 8c "replay mode"): on != 0 makes the following steps run the reference's
+ * greedy 8-wide batch scheduler (scheduleConstraintsSIMD, constraints.cpp:51-184) over the step's contacts in emission order and sweep
+ * the batches one after the other (constraints.cpp:3618-3709) instead of the device's own schedule.  A parity facility (one workgroup
+ * sweeps all contacts); mi_debug_read_replay_batches returns the last step's batches, 8 entries each: schedule position | contact << 28,
+ * 0xFFFFFFFF = empty lane. */
+int mi_debug_set_replay(mi_world* w, int on);
+uint32_t mi_debug_num_replay_batches(mi_world* w);
+int mi_debug_read_replay_batches(mi_world* w, uint32_t* outEntries8PerBatch);
 /* Developer timeline of the cluster contact sweep: enable != 0 allocates it (16 rows of 32 u64 per workgroup of the solve launch), out (may be
  * NULL) receives numSlots rows: per task and iteration the wall-clock stamps (10 ns ticks) "shared bodies acquired" / "colours done", the cost of
  * every colour step of iteration 10, and the stages of the task's colouring (csrc/k_cluster.hip documents the rows; tests/cluster_timeline.py prints them). */

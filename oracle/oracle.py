@@ -16,7 +16,7 @@ STATIC = 0xFFFFFFFF
 
 SPHERE, CAPSULE, CYLINDER, AABB, OBB, HULL = range(6)
 DISTANCE, BALL, FIXED, HINGE, CONE_TWIST, SLIDER = range(6)
-SOLVER_SCALAR, SOLVER_WIDE8, SOLVER_CUSTOM = 0, 1, 2
+SOLVER_SCALAR, SOLVER_WIDE8, SOLVER_CUSTOM, SOLVER_REPLAY = 0, 1, 2, 3  # REPLAY: the reference's batch order (scheduleConstraintsSIMD) with the device's row-form arithmetic
 
 COLLIDER_DTYPE = np.dtype([("shape", "<f4", 10), ("restitution", "<f4"), ("friction", "<f4"), ("density", "<f4"),
                            ("type", "<u4"), ("objectType", "<u4"), ("objectIndex", "<u4")])

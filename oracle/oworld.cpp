@@ -62,7 +62,7 @@ struct physics_settings
 	u32 simdBroadPhase, simdNarrowPhase, simdConstraintSolver;
 };
 
-enum solver_mode : u32 { solver_scalar = 0, solver_wide8 = 1, solver_custom_order = 2 };
+enum solver_mode : u32 { solver_scalar = 0, solver_wide8 = 1, solver_custom_order = 2, solver_replay = 3 };
 
 struct world
 {
@@ -871,6 +871,7 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 	{
 		w.contactConstraints.resize(numContacts);
 		for (u32 i = 0; i < numContacts; ++i) initializeCollisionConstraint(w.contactConstraints[i], rbs, w.contacts[i], w.contactBodyPairs[i], dt);
+		if (mode == solver_replay) scheduleConstraintsSIMD(w.contactBodyPairs.data(), numContacts, dummyRigidBodyIndex, w.contactSlots);
 	}
 
 	stageEnd(2);
@@ -883,6 +884,17 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 		for (u32 i : cO) solveConeTwistConstraint(cU[i], rbs);
 		for (u32 i : sO) solveSliderConstraint(sU[i], rbs);
 		if (mode == solver_wide8) { solveCollisionBatchesWide(batches, rbs); }
+		else if (mode == solver_replay) // the reference's batch order (scheduleConstraintsSIMD), each batch's constraints in the device's row-form arithmetic
+		{
+			for (const sched_slot& slot : w.contactSlots)
+				for (u32 l = 0; l < SCHED_W; ++l)
+				{
+					u32 ci = slot.indices[l];
+					bool padding = false; // (empty lanes duplicate lane 0: the SIMD code solves it again with identical operands)
+					for (u32 m = 0; m < l; ++m) if (slot.indices[m] == ci) padding = true;
+					if (!padding && ci < numContacts) solveCollisionConstraintRowForm(w.contactConstraints[ci], w.contacts[ci], w.contactBodyPairs[ci], rbs);
+				}
+		}
 		else if (mode == solver_custom_order)
 		{
 			if (w.rowForm) { for (u32 ci : w.customOrder) { if (ci < numContacts) solveCollisionConstraintRowForm(w.contactConstraints[ci], w.contacts[ci], w.contactBodyPairs[ci], rbs); } }

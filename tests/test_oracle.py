@@ -403,6 +403,20 @@ def test_row_form_against_reference_formula(oracle, name, steps):
         assert dpos <= 1e-2
 
 
+@pytest.mark.parametrize("name,steps", [("c1", 120), ("c2_small", 60)])
+def test_replay_order_against_the_wide_solver(oracle, name, steps):
+    """SOLVER_REPLAY (what the device's replay mode is compared with bit for bit: the reference's batch order, the device's row
+    arithmetic) against SOLVER_WIDE8 (the same batch order with the reference's 8-wide arithmetic, constraints.cpp:3618-3709): same
+    order, different rounding — rounding-level agreement over the first steps with contacts."""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name(name)
+    a = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_WIDE8))
+    b = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_REPLAY))
+    deltas = _first_contact_deltas(a, b, scene, steps)
+    print(name, "replay order (row arithmetic) vs the 8-wide solver: relative velocity difference over the first contact steps", ["%.1e" % d for d in deltas])
+    assert len(deltas) >= 5 and max(deltas[:2]) <= 1e-6
+
+
 def test_avx2_semantics_delta(oracle):
     """The reference's 8-wide path normalises the friction direction with _mm256_rsqrt_ps (12-bit estimate, no Newton step:
     math_simd.h:283-289); the oracle's 8-wide path uses exact 1/sqrt unless asked otherwise.  The distance between the two is the
