@@ -107,7 +107,8 @@ def _worker(rank, world_size, port, steps, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_slabs_match_single_world(tmp_path, mi):
+@pytest.mark.parametrize("ranks", [2, 3])        # 3: the middle rank packs and applies a message on either side
+def test_two_slabs_match_single_world(tmp_path, mi, ranks):
     from directx_renderer_kurth_amd import scenes, parallel
     steps = 40
     scene = scenes.by_name("c3_small")
@@ -116,16 +117,16 @@ def test_two_slabs_match_single_world(tmp_path, mi):
         w.step_internal(scene.dt)
     ref_t, ref_v = w.transforms(1), w.velocities()
     w.close()
-    mp.spawn(_worker, args=(2, _free_port(), steps, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(ranks, _free_port(), steps, str(tmp_path)), nprocs=ranks, join=True)
     t = np.load(os.path.join(str(tmp_path), "t.npy")); v = np.load(os.path.join(str(tmp_path), "v.npy"))
     sent, active, syncs, axis, recuts = np.load(os.path.join(str(tmp_path), "stats.npy"))
     assert np.isfinite(t).all() and sent > 0 and active < scene.num_bodies
     assert recuts == 2                            # steps 15 and 30: ownership re-derived from the all-reduced state, the partition asserts above held through them
     assert syncs == steps                         # the rehearsal path stages through the host once per step; the RCCL path adds none
     x0 = np.array([b[0] for b in scene.bodies], np.float64)[:, int(axis)]
-    cut = parallel.quantile_cuts(x0, 2)[0]
+    cuts = np.asarray(parallel.quantile_cuts(x0, ranks))
     err = np.abs(t[:, :3] - ref_t[:, :3]).max(axis=1)
-    far = np.abs(x0 - cut) > 5.0
+    far = np.abs(x0[:, None] - cuts[None, :]).min(axis=1) > 5.0
     # Gauss-Seidel inside a slab, block-Jacobi across the cut, and each slab orders its own contacts (the cluster sweep cuts its
     # tasks along Morton curves over the slab's own bounding box, so the solve order differs from the single world's everywhere,
     # not only at the cut): the pile as a whole stays the same pile and bodies not yet in contact follow the single-world
