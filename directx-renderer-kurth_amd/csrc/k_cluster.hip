@@ -271,6 +271,85 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 	}
 }
 
+// ---- the partition cached between re-sorts -------------------------------------------------------------------------------------
+// Bodies move a fraction of their size per step and the pile's contacts change by well under a per cent per step, so the chunk
+// boundaries of a phase (which chunk a body's curve position belongs to) are computed with the full pipeline — weights, scans,
+// one assignment pass per phase — only on the steps that also re-sort the bodies along the curves; in between, the stored chunk of
+// every body per phase decides where a manifold goes, in ONE pass without scans.  Any partition is valid; a stale one only lets the
+// tasks' sizes drift by the few per cent the pile changes in those steps (the refresh chunks are cut 4 % short for that).
+__global__ void __launch_bounds__(256) k_cl_store_chunks(u32 nb, u32 taskWeight, u32 maxTasks, const u32* __restrict__ rank, const u32* __restrict__ cum, const u32* __restrict__ rep, u32* __restrict__ chunk)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nb) return;
+	u32 t = cum[rank[rep ? rep[i] : i]] / clEffectiveWeight(taskWeight, cum[nb], maxTasks);
+	chunk[i] = min(t, CL_MAX_TASKS - 1u);
+}
+__global__ void __launch_bounds__(256) k_cl_assign_cached(u32* counters, u32 nb, u32 numParts, u32 withJoints, const uint4* __restrict__ actIds, const u32* __restrict__ chunk,
+	u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask)
+{
+	const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 numActive = counters[CTR_NUM_ACTIVE];
+	const bool live = j < numActive;
+	const bool dumpAll = numActive <= CL_REST_CAP && !withJoints;
+	u32* remainSub = taskCount + CL_MAX_PHASES * CL_MAX_TASKS * CL_SUBCOUNTERS;
+	u32 key = CL_MAX_PARTS * CL_MAX_TASKS, phase = numParts; // the rest task unless a phase takes it
+	uint4 ids = make_uint4(0, 0, 0, 0);
+	bool da = false, db = false;
+	if (live)
+	{
+		ids = actIds[j];
+		da = ids.x < nb; db = ids.y < nb;
+		if (!dumpAll)
+			for (u32 p = 0; p < numParts; ++p)
+			{
+				const u32* c = chunk + (size_t)p * (nb + 1u);
+				u32 ta = da ? c[ids.x] : 0u, tb = db ? c[ids.y] : 0u;
+				if (!da) ta = tb;
+				if (!db) tb = ta;
+				if (ta == tb) { key = p * CL_MAX_TASKS + ta; phase = p; break; }
+			}
+	}
+	// manifolds still unassigned when phase q + 1 starts (statistics; the host adapts the number of phases from them)
+	for (u32 q = 0; q < numParts; ++q)
+	{
+		u32 numLeft = (u32)__syncthreads_count(live && phase > q);
+		if (threadIdx.x == 0 && numLeft) atomicAdd(&remainSub[(q + 1u) * CL_REMAIN_SUBS + (blockIdx.x & (CL_REMAIN_SUBS - 1u))], numLeft);
+	}
+	if (!live) return;
+	taskKey[j] = key;
+	{
+		u64 todo = __ballot(1), mine = 0;
+		const u32 lane = threadIdx.x & 63u;
+		while (todo)
+		{
+			u32 leader = (u32)__ffsll((long long)todo) - 1u;
+			u32 k0 = __shfl(key, leader);
+			u64 same = __ballot(key == k0) & todo;
+			if (key == k0) mine = same;
+			todo &= ~same;
+		}
+		const u32 myLeader = (u32)__ffsll((long long)mine) - 1u;
+		u32 base = 0;
+		if (lane == myLeader) base = atomicAdd(&taskCount[key * CL_SUBCOUNTERS + (blockIdx.x & (CL_SUBCOUNTERS - 1u))], (u32)__popcll(mine));
+		base = __shfl(base, myLeader);
+		taskPos[j] = base + (u32)__popcll(mine & ((1ull << lane) - 1ull));
+	}
+	const u32 ph = key / CL_MAX_TASKS;
+	if (da && !(__hip_atomic_load(&phaseMask[ids.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << ph))) atomicOr(&phaseMask[ids.x], 1u << ph);
+	if (db && !(__hip_atomic_load(&phaseMask[ids.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << ph))) atomicOr(&phaseMask[ids.y], 1u << ph);
+}
+__global__ void __launch_bounds__(256) k_cl_joint_assign_cached(u32 numJoints, const uint4* __restrict__ table, const u32* __restrict__ chunk0, u32* __restrict__ jointTask, u32* __restrict__ jointPos,
+	u32* __restrict__ jointCount, u32* __restrict__ phaseMask)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= numJoints) return;
+	uint4 e = table[i];
+	u32 t = chunk0[e.z]; // (the chunk of the island's representative: k_cl_store_chunks)
+	jointTask[i] = t;
+	jointPos[i] = atomicAdd(&jointCount[t], 1u);
+	atomicOr(&phaseMask[e.z], 1u); atomicOr(&phaseMask[e.w], 1u);
+}
+
 // One workgroup: exclusive scan of the per-task counts -> first slot of every task; tasks per phase; end of schedule.
 __global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters, u32 numParts, const u32* __restrict__ taskCount, u32* __restrict__ taskStart, const u32* __restrict__ jointCount, u32* __restrict__ jointStart)
 {
@@ -1323,8 +1402,10 @@ void launch_cluster_build(World& w, u32 numPairs)
 	// their size per step, so the order is refreshed every few steps only (four radix sorts of all bodies), at once when bodies were
 	// added and after a snapshot was taken or restored (so that a restored world and its original keep making the same choices).
 	const u32 P = CL_MAX_PARTS; // all curves, whatever the number of partition phases in use: that number adapts from step to step
+	bool refresh = false; // this step re-sorts the bodies and re-cuts the chunks; the steps in between reuse the stored chunks
 	if (w.clusterSortDue || w.clusterSortAge >= w.clusterSortInterval || w.clusterSortBodies != nb)
 	{
+		refresh = true;
 		ClShifts sh; u32 maxShift = 0;
 		for (u32 p = 0; p < CL_MAX_PARTS; ++p) for (u32 k = 0; k < 3; ++k) { sh.s[p][k] = w.clusterShift[p][k]; maxShift = std::max(maxShift, sh.s[p][k]); }
 		hipLaunchKernelGGL(k_cl_bbox, dim3(std::min<u32>(bgrid.x, 64u)), block, 0, w.stream, nb, w.cog.p, w.simMask.p, w.dCounters.p);
@@ -1346,17 +1427,33 @@ void launch_cluster_build(World& w, u32 numPairs)
 	w.clJointClassStart.ensure((size_t)CL_MAX_TASKS * (CL_MAX_JOINT_CLASSES + 2u), w.stream);
 	if (w.lastError) return;
 	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.clJointCount.p, w.dCounters.p);
-	hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, rep, w.clWsum.p, w.clTaskKey.p);
-	if (nj) hipLaunchKernelGGL(k_cl_joint_weights, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clRank.p, rep, w.clWsum.p);
 	const u32 maxTasks = std::min<u32>(CL_MAX_TASKS / CL_TASKS_PER_PHASE, w.clusterBlocks) - std::min<u32>(8u, w.clusterBlocks / 8u); // per phase, with a margin for the chunks' rounding
-	for (u32 p = 0; p < parts; ++p)
+	w.clChunk.ensure((size_t)CL_MAX_PARTS * nb1, w.stream);
+	if (w.lastError) return;
+	if (!w.useChunkCache || w.clChunkParts < parts || w.clChunkJointVersion != w.jointVersion || w.clChunkWithJoints != withJoints) refresh = true;
+	if (refresh)
 	{
-		u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
-		prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
-		hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, p ? w.clusterTaskWeightLater : w.clusterTaskWeight, maxTasks, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
-			w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, p == 0 ? rep : nullptr);
-		if (p == 0 && nj) // (cum still holds phase 0's scan)
-			hipLaunchKernelGGL(k_cl_joint_assign, dim3((nj + 255) / 256), block, 0, w.stream, nj, nb, w.clusterTaskWeight, maxTasks, w.clJointTable.p, w.clRank.p, rep, w.clCum.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
+		// (with the cache on, the chunks are cut 4 % short: the pile may grow until the next refresh)
+		const u32 weight0 = w.useChunkCache ? w.clusterTaskWeight - (u32)((u64)w.clusterTaskWeight * w.chunkHeadroomPercent / 100u) : w.clusterTaskWeight, weightLater = w.useChunkCache ? w.clusterTaskWeightLater - (u32)((u64)w.clusterTaskWeightLater * w.chunkHeadroomPercent / 100u) : w.clusterTaskWeightLater;
+		hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, rep, w.clWsum.p, w.clTaskKey.p);
+		if (nj) hipLaunchKernelGGL(k_cl_joint_weights, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clRank.p, rep, w.clWsum.p);
+		for (u32 p = 0; p < parts; ++p)
+		{
+			u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
+			prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
+			hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, p ? weightLater : weight0, maxTasks, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
+				w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, p == 0 ? rep : nullptr);
+			if (p == 0 && nj) // (cum still holds phase 0's scan)
+				hipLaunchKernelGGL(k_cl_joint_assign, dim3((nj + 255) / 256), block, 0, w.stream, nj, nb, weight0, maxTasks, w.clJointTable.p, w.clRank.p, rep, w.clCum.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
+			if (w.useChunkCache)
+				hipLaunchKernelGGL(k_cl_store_chunks, bgrid, block, 0, w.stream, nb, p ? weightLater : weight0, maxTasks, w.clRank.p + (size_t)p * nb1, w.clCum.p, p == 0 ? rep : nullptr, w.clChunk.p + (size_t)p * nb1);
+		}
+		w.clChunkParts = parts; w.clChunkJointVersion = w.jointVersion; w.clChunkWithJoints = withJoints;
+	}
+	else
+	{
+		hipLaunchKernelGGL(k_cl_assign_cached, mgrid, block, 0, w.stream, w.dCounters.p, nb, parts, withJoints ? 1u : 0u, w.actIds.p, w.clChunk.p, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p);
+		if (nj) hipLaunchKernelGGL(k_cl_joint_assign_cached, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clChunk.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p);
 	}
 	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, parts, w.clTaskCount.p, w.clTaskStart.p, nj ? w.clJointCount.p : (u32*)nullptr, nj ? w.clJointStart.p : (u32*)nullptr);
 	if (nj) hipLaunchKernelGGL(k_cl_joint_scatter, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTask.p, w.clJointPos.p, w.clJointStart.p, w.clJointList.p);
