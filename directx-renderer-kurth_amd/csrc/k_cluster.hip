@@ -284,8 +284,11 @@ __global__ void __launch_bounds__(256) k_cl_store_chunks(u32 nb, u32 taskWeight,
 	u32 t = cum[rank[rep ? rep[i] : i]] / clEffectiveWeight(taskWeight, cum[nb], maxTasks);
 	chunk[i] = min(t, CL_MAX_TASKS - 1u);
 }
-__global__ void __launch_bounds__(256) k_cl_assign_cached(u32* counters, u32 nb, u32 numParts, u32 withJoints, const uint4* __restrict__ actIds, const u32* __restrict__ chunk,
-	u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask)
+// numCached: the phases placed from the stored chunks (1: the first phase only — the later phases, a quarter of the manifolds, keep
+// the per-step pipeline on what is left, which keeps their tasks at the size their fast path needs).  What the cached phases leave
+// goes on to phase numCached (its weight onto that phase's curve), or to the rest task when there is none.
+__global__ void __launch_bounds__(256) k_cl_assign_cached(u32* counters, u32 nb, u32 numParts, u32 numCached, u32 withJoints, const uint4* __restrict__ actIds, const u32* __restrict__ chunk,
+	const u32* __restrict__ rankNext, u32* __restrict__ wsumNext, u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask)
 {
 	const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
 	const u32 numActive = counters[CTR_NUM_ACTIVE];
@@ -300,7 +303,7 @@ __global__ void __launch_bounds__(256) k_cl_assign_cached(u32* counters, u32 nb,
 		ids = actIds[j];
 		da = ids.x < nb; db = ids.y < nb;
 		if (!dumpAll)
-			for (u32 p = 0; p < numParts; ++p)
+			for (u32 p = 0; p < numCached; ++p)
 			{
 				const u32* c = chunk + (size_t)p * (nb + 1u);
 				u32 ta = da ? c[ids.x] : 0u, tb = db ? c[ids.y] : 0u;
@@ -310,12 +313,20 @@ __global__ void __launch_bounds__(256) k_cl_assign_cached(u32* counters, u32 nb,
 			}
 	}
 	// manifolds still unassigned when phase q + 1 starts (statistics; the host adapts the number of phases from them)
-	for (u32 q = 0; q < numParts; ++q)
+	const bool goesOn = live && phase == numParts && numCached < numParts && !dumpAll; // left by the cached phases, with a pipeline phase to go to
+	for (u32 q = 0; q < numCached; ++q)
 	{
 		u32 numLeft = (u32)__syncthreads_count(live && phase > q);
 		if (threadIdx.x == 0 && numLeft) atomicAdd(&remainSub[(q + 1u) * CL_REMAIN_SUBS + (blockIdx.x & (CL_REMAIN_SUBS - 1u))], numLeft);
 	}
 	if (!live) return;
+	if (goesOn)
+	{
+		taskKey[j] = CL_UNASSIGNED;
+		u32 ra = rankNext[ids.x], rb = rankNext[ids.y];
+		atomicAdd(&wsumNext[min(ra, rb)], clWeight(ids.z));
+		return;
+	}
 	taskKey[j] = key;
 	{
 		u64 todo = __ballot(1), mine = 0;
@@ -1434,7 +1445,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 	if (refresh)
 	{
 		// (with the cache on, the chunks are cut 4 % short: the pile may grow until the next refresh)
-		const u32 weight0 = w.useChunkCache ? w.clusterTaskWeight - (u32)((u64)w.clusterTaskWeight * w.chunkHeadroomPercent / 100u) : w.clusterTaskWeight, weightLater = w.useChunkCache ? w.clusterTaskWeightLater - (u32)((u64)w.clusterTaskWeightLater * w.chunkHeadroomPercent / 100u) : w.clusterTaskWeightLater;
+		const u32 weight0 = w.useChunkCache ? w.clusterTaskWeight - (u32)((u64)w.clusterTaskWeight * w.chunkHeadroomPercent / 100u) : w.clusterTaskWeight, weightLater = (w.useChunkCache && w.chunkCachedPhases > 1u) ? w.clusterTaskWeightLater - (u32)((u64)w.clusterTaskWeightLater * w.chunkHeadroomPercent / 100u) : w.clusterTaskWeightLater;
 		hipLaunchKernelGGL(k_cl_weights0, mgrid, block, 0, w.stream, w.dCounters.p, nb, w.actIds.p, w.clRank.p, rep, w.clWsum.p, w.clTaskKey.p);
 		if (nj) hipLaunchKernelGGL(k_cl_joint_weights, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clRank.p, rep, w.clWsum.p);
 		for (u32 p = 0; p < parts; ++p)
@@ -1452,8 +1463,17 @@ void launch_cluster_build(World& w, u32 numPairs)
 	}
 	else
 	{
-		hipLaunchKernelGGL(k_cl_assign_cached, mgrid, block, 0, w.stream, w.dCounters.p, nb, parts, withJoints ? 1u : 0u, w.actIds.p, w.clChunk.p, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p);
+		const u32 cached = std::min(parts, w.chunkCachedPhases);
+		hipLaunchKernelGGL(k_cl_assign_cached, mgrid, block, 0, w.stream, w.dCounters.p, nb, parts, cached, withJoints ? 1u : 0u, w.actIds.p, w.clChunk.p,
+			w.clRank.p + (size_t)std::min(cached, CL_MAX_PARTS - 1) * nb1, w.clWsum.p + (size_t)std::min(cached, CL_MAX_PARTS - 1) * nb1, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p);
 		if (nj) hipLaunchKernelGGL(k_cl_joint_assign_cached, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clChunk.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p);
+		for (u32 p = cached; p < parts; ++p) // the later phases: the per-step pipeline on what is left
+		{
+			u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
+			prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
+			hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, p ? w.clusterTaskWeightLater : w.clusterTaskWeight, maxTasks, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
+				w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, (const u32*)nullptr);
+		}
 	}
 	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, parts, w.clTaskCount.p, w.clTaskStart.p, nj ? w.clJointCount.p : (u32*)nullptr, nj ? w.clJointStart.p : (u32*)nullptr);
 	if (nj) hipLaunchKernelGGL(k_cl_joint_scatter, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTask.p, w.clJointPos.p, w.clJointStart.p, w.clJointList.p);

@@ -63,6 +63,7 @@ World::World(int dev) : device(dev)
 	if (const char* e = getenv("MI_CLUSTER_TASK")) { clusterTaskWeight = 64u * (u32)std::max(16, atoi(e)); clusterTaskWeightLater = std::min(clusterTaskWeight, 64u * 560u); }  // manifolds per task
 	if (getenv("MI_PHYSICS_REPLAY")) replayReferenceOrder = true;
 	if (getenv("MI_CLUSTER_NO_CHUNK_CACHE")) useChunkCache = false;
+	if (const char* e = getenv("MI_CLUSTER_CHUNK_PHASES")) chunkCachedPhases = (u32)std::min(4, std::max(1, atoi(e)));
 	if (const char* e = getenv("MI_CLUSTER_CHUNK_HEADROOM")) chunkHeadroomPercent = (u32)std::min(50, std::max(0, atoi(e)));
 	if (const char* e = getenv("MI_CLUSTER_PREDICT_DIV")) clusterPredictDiv = (u32)std::max(2, atoi(e));
 	if (const char* e = getenv("MI_CLUSTER_POLL_SLEEP")) clusterPollSleep = (u32)std::max(0, atoi(e));
