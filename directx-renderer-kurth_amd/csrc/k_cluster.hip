@@ -123,6 +123,16 @@ __global__ void __launch_bounds__(256) k_cl_ranks(u32 nb, u32 numParts, const u3
 // first and gather in the low colours: a colour's sweep time is that of its longest manifold, and this keeps the 2-4-contact ones
 // (20 % of a mixed pile) out of most colours.  Then a pseudo-random priority (hash of the narrowphase slot and the round), then
 // the position inside the task, which makes the bid unique.
+// Where phase p's task 0 goes: task t of phase p belongs to workgroup (clPhaseOffset + t) % G.  The first phase starts at workgroup 0;
+// behind it the phases are placed LAST PHASE FIRST (rest task, then the last partition phase, ...): the workgroups the first phase
+// leaves free run their task from registers, and the few tasks of the last phases — every iteration's critical path runs through
+// them — get those places before the second phase's many tasks do.
+MI_DEV u32 clPhaseOffset(const u32* counters, u32 p)
+{
+	u32 off = p ? counters[CTR_CL_NUM_TASKS] : 0u;
+	for (u32 q = CL_MAX_PHASES - 1u; q > p && p; --q) off += counters[CTR_CL_NUM_TASKS + q];
+	return off;
+}
 // A phase may not have more tasks than the solve launch has workgroups (task t of a phase runs on workgroup (offset + t) % G, all
 // of them resident): when the pile outgrows "G tasks of the configured weight", the chunks grow instead.  cum[nb] = total weight.
 MI_DEV u32 clEffectiveWeight(u32 taskWeight, u32 totalWeight, u32 maxTasks)
@@ -453,12 +463,10 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 	// Task t of phase p is built by workgroup (tasks of the earlier phases + t) % G — the rotation the solve launch uses — so that
 	// the later phases' tasks go to the workgroups the first phase left idle first, and nobody builds more than
 	// ceil(tasks / G) + 1 of them (by key order workgroup 0 built one task of EVERY phase: 4 x 35 us on the kernel's critical path).
-	u32 phaseOffset = 0;
 	for (u32 ph = 0; ph < CL_MAX_PHASES; ++ph)
 	{
 	const u32 tasksInPhase = counters[CTR_CL_NUM_TASKS + ph];
-	const u32 tFirst = (blockIdx.x + gridDim.x - (phaseOffset % gridDim.x)) % gridDim.x;
-	phaseOffset += tasksInPhase;
+	const u32 tFirst = (blockIdx.x + gridDim.x - (clPhaseOffset(counters, ph) % gridDim.x)) % gridDim.x;
 	for (u32 key = ph * CL_MAX_TASKS + tFirst; key < ph * CL_MAX_TASKS + min(tasksInPhase, CL_MAX_TASKS); key += gridDim.x)
 	{
 		u32 first = taskStart[key * CL_SUBCOUNTERS], n = taskStart[(key + 1u) * CL_SUBCOUNTERS] - first;
@@ -957,10 +965,10 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 		{
 			u32 tasksInPhase = A.counters[CTR_CL_NUM_TASKS + p];
 			if (tasksInPhase > CL_TASKS_PER_PHASE * G) bad = true;
-			// task t of phase p runs on workgroup (off + t) % G; a phase with more tasks than workgroups wraps around (its tasks share
-			// no body, so a workgroup may run two of them one after the other)
+			// task t of phase p runs on workgroup (clPhaseOffset + t) % G; a phase with more tasks than workgroups wraps around (its tasks
+			// share no body, so a workgroup may run two of them one after the other)
+			off = clPhaseOffset(A.counters, p);
 			u32 t = (blockIdx.x + G - (off % G)) % G;
-			off += tasksInPhase;
 			for (; t < tasksInPhase && !bad; t += G)
 			{
 				u32 key = p * CL_MAX_TASKS + t;

@@ -187,7 +187,7 @@ struct World
 	u32 clusterLdsBytes = 0, clusterBlocks = 0, clusterCooldown = 0;
 	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clExtra, clTaskCount, clTaskStart, clBodyList, clBodyUsers, clRankInfo, clSharedSlot;
 	DevBuf<uint8_t> clTasks;
-	DevBuf<u32> clChunk; u32 clChunkParts = 0, clChunkJointVersion = ~0u; bool clChunkWithJoints = false, useChunkCache = true; u32 chunkHeadroomPercent = 4, chunkCachedPhases = CL_MAX_PARTS; // chunk of every body per phase, kept between re-sorts (MI_CLUSTER_NO_CHUNK_CACHE=1: the full partition pipeline every step)
+	DevBuf<u32> clChunk; u32 clChunkParts = 0, clChunkJointVersion = ~0u; bool clChunkWithJoints = false, useChunkCache = true; u32 chunkHeadroomPercent = 10, chunkCachedPhases = CL_MAX_PARTS; // chunk of every body per phase, kept between re-sorts (MI_CLUSTER_NO_CHUNK_CACHE=1: the full partition pipeline every step)
 	// joints inside the cluster sweep: island representative per body (jointed bodies must share a task), the joints of all types in
 	// (type, colour) order {type | class << 8, index in the type's colour-sorted arrays, body a, body b}, and the per-step lists
 	DevBuf<u32> clRep, clJointTask, clJointPos, clJointCount, clJointStart, clJointList; DevBuf<uint4> clJointTable; DevBuf<uint2> clTaskJoints; DevBuf<u32> clJointClassStart;
