@@ -740,8 +740,11 @@ struct EpaWave
 {
 	float pa[EPA_MAX_POINTS][3], pb[EPA_MAX_POINTS][3];          // support points on A and B; minkowski = a - b (bit-identical to the stored one)
 	float tnx[EPA_MAX_TRIANGLES], tny[EPA_MAX_TRIANGLES], tnz[EPA_MAX_TRIANGLES], tdist[EPA_MAX_TRIANGLES];
-	u32 ta[EPA_MAX_TRIANGLES], tb[EPA_MAX_TRIANGLES], tc[EPA_MAX_TRIANGLES], teA[EPA_MAX_TRIANGLES], teB[EPA_MAX_TRIANGLES], teC[EPA_MAX_TRIANGLES], tactive[EPA_MAX_TRIANGLES];
-	u32 ea[EPA_MAX_EDGES], eb[EPA_MAX_EDGES], etA[EPA_MAX_EDGES], etB[EPA_MAX_EDGES], refs[EPA_MAX_EDGES];
+	// (indices are below 65535 = EPA_NONE32: 16 bits each keep a wave's polytope at 6.3 KB instead of 9.6, i.e. more resident workgroups)
+	uint16_t ta[EPA_MAX_TRIANGLES], tb[EPA_MAX_TRIANGLES], tc[EPA_MAX_TRIANGLES], teA[EPA_MAX_TRIANGLES], teB[EPA_MAX_TRIANGLES], teC[EPA_MAX_TRIANGLES];
+	uint8_t tactive[EPA_MAX_TRIANGLES];
+	uint16_t ea[EPA_MAX_EDGES], eb[EPA_MAX_EDGES], etA[EPA_MAX_EDGES], etB[EPA_MAX_EDGES];
+	u32 refs[EPA_MAX_EDGES];
 	u32 border[EPA_MAX_BORDER], newEdgePerPoint[EPA_MAX_POINTS];
 };
 #define EPA_NONE32 0xFFFFu
