@@ -720,8 +720,10 @@ void World::countPreviousStep()
 	if (had && lastStepCluster) clusterFailStreak = 0; // (a give-up never gets here: recoverFlow clears lastStepCluster)
 	if (had && lastStepCluster && !clusterPartsFixed)
 	{
-		if (hCounters[CTR_CL_PHASE_COUNT + CL_MAX_PARTS] > 768u && clusterParts < CL_MAX_PARTS) ++clusterParts;
-		else if (clusterParts > 1 && hCounters[CTR_CL_PHASE_COUNT + clusterParts - 1] == 0 && hCounters[CTR_CL_REMAIN + clusterParts - 1] < 384u) --clusterParts;
+		// (every phase costs a hand-over per iteration: the last partition phase is dropped as soon as what it holds would fit the rest task too)
+		const u32 rest = hCounters[CTR_CL_PHASE_COUNT + CL_MAX_PARTS], last = hCounters[CTR_CL_PHASE_COUNT + clusterParts - 1];
+		if (rest > 960u && clusterParts < CL_MAX_PARTS) ++clusterParts;
+		else if (clusterParts > 1 && last + rest < 800u && hCounters[CTR_CL_REMAIN + clusterParts - 1] < 800u) --clusterParts;
 	}
 	sumContacts += stats.numContacts; sumManifolds += stats.numCollisions; sumColors += stats.numColors; sumPairs += prevTruePairs; sumProbes += stats.flowProbes; sumSteps++;
 }
