@@ -74,7 +74,7 @@ EXPORTED_SYMBOLS = [
     "mi_add_cloth", "mi_cloth_set_fixed_vertices", "mi_cloth_set_properties", "mi_set_cloth_iterations", "mi_num_cloths", "mi_cloth_num_particles", "mi_cloth_read",
     "mi_test_physics_interaction", "mi_apply_force_torque", "mi_set_velocity",
     "mi_set_transform", "mi_write_transforms", "mi_write_velocities", "mi_step", "mi_step_internal", "mi_synchronize", "mi_read_transforms", "mi_read_velocities", "mi_read_mass_properties",
-    "mi_get_stats", "mi_enable_validation", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_slab_configure", "mi_slab_message_bytes", "mi_slab_pack", "mi_slab_unpack", "mi_slab_read_codes", "mi_debug_num_pairs", "mi_debug_read_pairs",
+    "mi_get_stats", "mi_enable_validation", "mi_enable_stage_timing", "mi_num_bodies", "mi_num_colliders", "mi_device_pointers", "mi_state_to_device_buffers", "mi_state_from_device_buffers", "mi_slab_configure", "mi_slab_message_bytes", "mi_slab_pack", "mi_slab_unpack", "mi_slab_read_codes", "mi_debug_num_pairs", "mi_debug_read_pairs", "mi_debug_sorting_axis",
     "mi_debug_read_world_colliders", "mi_debug_num_manifold_slots", "mi_debug_read_manifolds", "mi_debug_num_colors", "mi_debug_read_schedule",
     "mi_debug_read_joint_order", "mi_debug_read_body_state", "mi_debug_flow_trace",
     "mi_debug_set_replay", "mi_debug_num_replay_batches", "mi_debug_read_replay_batches",
@@ -441,6 +441,12 @@ class World:
         if len(out):
             self._check(self.lib.mi_debug_read_pairs(self.w, _p(out)))
         return out
+
+    def sorting_axis(self):
+        """(axis the last step oriented its equal-type pairs by, axis of the next step): the reference's sap_context::sortingAxis."""
+        out = np.zeros(2, np.uint32)
+        self._check(self.lib.mi_debug_sorting_axis(self.w, _p(out)))
+        return int(out[0]), int(out[1])
 
     def world_colliders(self):
         n = self.num_colliders

@@ -129,28 +129,47 @@ MI_DEV float buildCollider(u32 i, u32 nb, const ColliderRec* __restrict__ colLoc
 }
 
 // One lane per collider; the kernel also produces the broadphase cell size (max extent; max() is order-independent, so the atomic is
-// deterministic; CTR_CELL_SIZE was reset at the end of the previous broadphase) and clears the grid's cell table.
+// deterministic; CTR_CELL_SIZE was reset at the end of the previous broadphase), clears the grid's cell table, and leaves per
+// workgroup the sums the reference's sweep picks its NEXT sorting axis from (sum of the AABB centres and of their squares,
+// collision_broad.cpp:374-376; reduced in a fixed order by k_finish_pair_count, in double: the reference adds them up in float, one
+// collider after the other, which no parallel sum reproduces bit for bit — the two can disagree on the axis only where two
+// variances agree to within that float sum's rounding).
 __global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
 	const float4* __restrict__ colStaticPose, const uint8_t* __restrict__ simMask, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax,
-	u32* __restrict__ counters, u32* __restrict__ cellStart, u32 hashTableSize, const float4* __restrict__ hullInfo)
+	u32* __restrict__ counters, u32* __restrict__ cellStart, u32 hashTableSize, const float4* __restrict__ hullInfo, double* __restrict__ sapPartial)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	float e = (i < nc) ? buildCollider(i, nb, colLocal, pose, colStaticPose, simMask, colWorld, aabbMin, aabbMax, hullInfo) : 0.f;
-	for (int o = 32; o > 0; o >>= 1) e = fmaxf(e, __shfl_xor(e, o));
+	double acc[7] = { 0., 0., 0., 0., 0., 0., 0. };
+	if (i < nc)
+	{
+		float4 mn = aabbMin[i], mx = aabbMax[i];
+		if (mn.x <= mx.x) // (an empty box = a body simulated elsewhere: not a collider of this world's sweep)
+		{
+			float cx = (mn.x + mx.x) * 0.5f, cy = (mn.y + mx.y) * 0.5f, cz = (mn.z + mx.z) * 0.5f; // bounding_box::getCenter
+			acc[0] = cx; acc[1] = cy; acc[2] = cz; acc[3] = (double)cx * cx; acc[4] = (double)cy * cy; acc[5] = (double)cz * cz; acc[6] = 1.;
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) { e = fmaxf(e, __shfl_xor(e, o)); for (int k = 0; k < 7; ++k) acc[k] += __shfl_xor(acc[k], o); }
 	__shared__ u32 sMax; // one global atomic per workgroup (same-address atomics serialise)
+	__shared__ double sAcc[4][7];
 	if (threadIdx.x == 0) sMax = 0;
 	__syncthreads();
-	if ((threadIdx.x & 63) == 0 && e > 0.f) atomicMax(&sMax, __float_as_uint(e));
+	if ((threadIdx.x & 63) == 0) { if (e > 0.f) atomicMax(&sMax, __float_as_uint(e)); for (int k = 0; k < 7; ++k) sAcc[threadIdx.x >> 6][k] = acc[k]; }
 	__syncthreads();
 	if (threadIdx.x == 0 && sMax) atomicMax(&counters[CTR_CELL_SIZE], sMax);
+	if (threadIdx.x < 7) sapPartial[(size_t)blockIdx.x * 7 + threadIdx.x] = ((sAcc[0][threadIdx.x] + sAcc[1][threadIdx.x]) + sAcc[2][threadIdx.x]) + sAcc[3][threadIdx.x];
 	for (u32 h = i; h < hashTableSize; h += gridDim.x * blockDim.x) cellStart[h] = 0xFFFFFFFFu; // EMPTY_CELL
 }
 
 void launch_build_colliders(World& w)
 {
 	if (!w.nc) return;
-	hipLaunchKernelGGL(k_build_colliders, dim3((w.nc + 255) / 256), dim3(256), 0, w.stream, w.nc, w.nb, w.colLocal.p, w.pose.p, w.colStaticPose.p,
-		w.simMask.p, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.cellStart.p, w.hashTableSize, w.hullInfo.p);
+	const u32 blocks = (w.nc + 255) / 256;
+	w.sapPartial.ensure((size_t)blocks * 7, w.stream);
+	if (w.lastError) return;
+	hipLaunchKernelGGL(k_build_colliders, dim3(blocks), dim3(256), 0, w.stream, w.nc, w.nb, w.colLocal.p, w.pose.p, w.colStaticPose.p,
+		w.simMask.p, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.cellStart.p, w.hashTableSize, w.hullInfo.p, w.sapPartial.p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

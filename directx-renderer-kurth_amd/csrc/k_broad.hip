@@ -178,12 +178,22 @@ __global__ void __launch_bounds__(256) k_pairs_pack(u32 nc, const u32* __restric
 	if (dst < pairCap) pairs[dst] = slab[i];
 }
 
-__global__ void k_finish_pair_count(u32 nc, const u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, u32* __restrict__ counters)
+// One wave.  Besides the pair count: the sorting axis the reference's sweep would use in the NEXT step = the axis of largest variance
+// of this step's AABB centres (collision_broad.cpp:443-444: variance = s2 - s * s / numColliders; x over y, x over z, y over z on
+// ties), from the per-workgroup sums of k_build_colliders added up in a fixed order.  It goes to the word of step + 1's parity, so
+// that a step whose start is run twice (World::stepInternal after a recovered cluster sweep) leaves this step's own axis alone.
+__global__ void k_finish_pair_count(u32 nc, const u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, u32* __restrict__ counters, const double* __restrict__ sapPartial, u32 sapBlocks, u32 stepParity)
 {
+	double acc[7] = { 0., 0., 0., 0., 0., 0., 0. };
+	for (u32 b = threadIdx.x; b < sapBlocks; b += 64u) for (int k = 0; k < 7; ++k) acc[k] += sapPartial[(size_t)b * 7 + k];
+	for (int o = 32; o > 0; o >>= 1) for (int k = 0; k < 7; ++k) acc[k] += __shfl_xor(acc[k], o);
 	if (threadIdx.x == 0 && blockIdx.x == 0)
 	{
 		counters[CTR_NUM_PAIRS] = nc ? pairOffset[nc - 1] + pairCount[nc - 1] : 0;
 		counters[CTR_CELL_SIZE] = 0; // nobody reads the cell size after the pair traversal: ready for the next step's atomicMax
+		const double n = acc[6] > 0. ? acc[6] : 1.;
+		const double vx = acc[3] - acc[0] * acc[0] / n, vy = acc[4] - acc[1] * acc[1] / n, vz = acc[5] - acc[2] * acc[2] / n;
+		counters[CTR_SAP_AXIS + (stepParity ^ 1u)] = (vx > vy) ? ((vx > vz) ? 0u : 2u) : ((vy > vz) ? 1u : 2u);
 	}
 }
 
@@ -238,7 +248,7 @@ void launch_broadphase_count(World& w)
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_SLAB>), dim3((u32)(((size_t)nc * PAIR_LANES + 255) / 256)), block, 0, w.stream, nc, mask, w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p, w.dCounters.p,
 		w.pairCount.p, w.pairOffset.p, w.pairSlab.p, 0u);
 	prim_exclusive_scan_u32(w, w.pairCount.p, w.pairOffset.p, nc);
-	hipLaunchKernelGGL(k_finish_pair_count, dim3(1), dim3(64), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.dCounters.p);
+	hipLaunchKernelGGL(k_finish_pair_count, dim3(1), dim3(64), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.dCounters.p, w.sapPartial.p, (nc + 255) / 256, w.stats.numInternalSteps & 1u);
 }
 
 void launch_broadphase_write(World& w, u32 numPairs)

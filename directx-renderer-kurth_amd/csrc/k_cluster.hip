@@ -1496,7 +1496,7 @@ void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd)
 {
 	if (itBegin >= itEnd) return;
 	size_t words = (size_t)(w.nb + 1) * CL_MAX_PHASES * 4; // one 32-byte hand-over record per (phase, body) at most
-	if (w.flow.cap < words) { w.flow.ensure(words, w.stream); w.flowEpoch = 0; }
+	if (w.flow.cap < words) { w.flow.ensure(words, w.stream); w.flowEpoch = 0; if (w.lastError) return; } // (a failed allocation leaves the old, smaller buffer: nothing may be launched over it)
 	if (w.flowEpoch == 0 || w.flowEpoch >= 0xFFFEu) // first use or the turn counter about to wrap: no stale record may ever match
 	{
 		MI_CHECK(hipMemsetAsync(w.flow.p, 0, sizeof(u64) * words, w.stream));

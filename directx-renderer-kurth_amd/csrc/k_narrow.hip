@@ -21,7 +21,11 @@ MI_DEV bool typeSupported(u32 t) { return t <= MI_HULL; }
 // ---------------------------------------------------------------------------------------------------------------
 // K5: prune + classify.  Reads the 16-B tag quarter of both colliders.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_classify(const u32* __restrict__ counters, u32 nb, const uint2* __restrict__ pairs, const ColliderRec* __restrict__ colWorld,
+// Equal types: the reference's sweep reports a pair as (collider whose start endpoint comes later on the sorting axis, the one already
+// active) (collision_broad.cpp:127) and the narrowphase swaps equal-type pairs (collision_narrow.cpp:2374), so A = the collider
+// whose box STARTS FIRST on this step's sorting axis.  Equal starts: the reference's order is that of its endpoint array (a stable
+// insertion sort carried over from earlier frames); here the lower collider index comes first.
+__global__ void __launch_bounds__(256) k_classify(const u32* __restrict__ counters, u32 nb, const uint2* __restrict__ pairs, const ColliderRec* __restrict__ colWorld, const float4* __restrict__ aabbMin, u32 stepParity,
 	u32* __restrict__ pairKey, u64* __restrict__ pairPacked)
 {
 	u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,7 +37,15 @@ __global__ void __launch_bounds__(256) k_classify(const u32* __restrict__ counte
 	bool rbA = bA < nb, rbB = bB < nb;
 	if ((rbA || rbB) && !(rbA && rbB && bA == bB) && typeSupported(tA) && typeSupported(tB)) // :2358-2369
 	{
-		if (!(tA < tB)) { u32 t = pr.x; pr.x = pr.y; pr.y = t; t = tA; tA = tB; tB = t; } // :2374 — swaps on equal types too
+		bool swap = tA > tB; // :2374: A = the lower type
+		if (tA == tB)
+		{
+			const u32 axis = counters[CTR_SAP_AXIS + stepParity];
+			float4 ma = aabbMin[pr.x], mb = aabbMin[pr.y];
+			float sa = axis == 0u ? ma.x : (axis == 1u ? ma.y : ma.z), sb = axis == 0u ? mb.x : (axis == 1u ? mb.y : mb.z);
+			swap = sb < sa || (sb == sa && pr.y < pr.x);
+		}
+		if (swap) { u32 t = pr.x; pr.x = pr.y; pr.y = t; t = tA; tA = tB; tB = t; }
 		u32 zone = (__float_as_uint(da.w) | __float_as_uint(db.w)) & 0xFFu; // a force-field / trigger collider is in the pair
 		key = zone ? KEY_ZONE : tA * 6 + tB;
 	}
@@ -1195,7 +1207,7 @@ void launch_narrowphase(World& w, u32 numPairs)
 		return;
 	}
 	dim3 grid((numPairs + 255) / 256), block(256);
-	hipLaunchKernelGGL(k_classify, grid, block, 0, w.stream, w.dCounters.p, w.nb, w.pairs.p, w.colWorld.p, w.pairKey.p, (u64*)w.pairsSorted.p + numPairs);
+	hipLaunchKernelGGL(k_classify, grid, block, 0, w.stream, w.dCounters.p, w.nb, w.pairs.p, w.colWorld.p, w.aabbMin.p, w.stats.numInternalSteps & 1u, w.pairKey.p, (u64*)w.pairsSorted.p + numPairs);
 	// sort (bucket key, packed pair): unsorted packed pairs live in the upper half of pairsSorted, sorted ones in the lower half
 	csort_pairs_u64(w, w.pairKey.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p + numPairs, (u64*)w.pairsSorted.p, numPairs, 64);
 	hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p);

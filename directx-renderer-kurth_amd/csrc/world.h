@@ -78,7 +78,8 @@ enum
 	CTR_BUCKET_START = 16,  // 65 words: first slot of narrowphase bucket key b (tA*6+tB); [64] unused
 	CTR_KEY_START = 96,     // (MI_MAX_COLORS+1)*4 + 1 words: first schedule slot of key colour*4 + (4-count); last = numManifolds
 	CTR_COLOR_BARRIER = 360,// 4 words: grid barrier of the fused colouring kernel (arrivals, 3 x manifolds left)
-	CTR_FLOW_CENSUS = 368,  // 16 words, unused (round 1's dataflow launch counted its workgroups per XCD here)
+	CTR_SAP_AXIS = 368,     // 2 words: the reference sweep's sorting axis (collision_broad.cpp:443-444) for internal step k at [k & 1]: written by step k - 1 from its AABB centres, read by k_classify
+	CTR_SAP_MASKED = 370,   // colliders with an empty AABB (bodies simulated by another GPU): not part of the axis statistic
 	CTR_REGION_START = 384, // 9 words: first position in flowOrder of XCD region r; [8] = numManifolds
 	CTR_REGION_CUTS = 400,  // 7 floats: region r holds bodies with cuts[r-1] <= x < cuts[r]
 	CTR_REGION_RANGE = 408, // 2 floats: [lo, hi] of the histogram that produces the next cuts
@@ -163,6 +164,7 @@ struct World
 	// broadphase
 	DevBuf<u32> hashKey, hashKeySorted, sortIdx, sortIdxSorted, cellStart, cellEnd, largeFlag, largeScan, largeList, pairCount, pairOffset;
 	DevBuf<u64> sCellKey; DevBuf<float4> sMin, sMax;
+	DevBuf<double> sapPartial;            // per workgroup of k_build_colliders: sum of the AABB centres (3), of their squares (3), colliders counted (1)
 	DevBuf<uint2> pairs, pairSlab;
 	u32 hashTableSize = 0;
 	// narrowphase

@@ -34,7 +34,7 @@ template <typename T> void DevBuf<T>::ensure(size_t n, hipStream_t s, bool keep)
 template <typename T> void DevBuf<T>::release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
 
 template struct DevBuf<float4>; template struct DevBuf<float2>; template struct DevBuf<uint2>; template struct DevBuf<uint4>; template struct DevBuf<u32>;
-template struct DevBuf<u64>; template struct DevBuf<uint8_t>; template struct DevBuf<float>; template struct DevBuf<ColliderRec>; template struct DevBuf<ManifoldRec>;
+template struct DevBuf<double>; template struct DevBuf<u64>; template struct DevBuf<uint8_t>; template struct DevBuf<float>; template struct DevBuf<ColliderRec>; template struct DevBuf<ManifoldRec>;
 
 World::World(int dev) : device(dev)
 {
@@ -801,7 +801,7 @@ int World::stepInternal(float dt, u32 iters)
 	// device), or global colouring + one launch per colour when it is switched off, recovering, or cannot hold the turn counters.
 	const bool clusterStep = useCluster && !replayReferenceOrder && !clusterCooldown && numPairs && iters && iters < 4096u && cluster_available(*this);
 	backupVelocities = clusterStep;                        // pre-solve velocities, in case the cluster sweep has to be redone (World::recoverFlow)
-	if (clusterStep) velBackup.ensure(2 * ((size_t)nb + 1), stream);
+	if (clusterStep) { velBackup.ensure(2 * ((size_t)nb + 1), stream); if (lastError) return lastError; } // (a failed allocation leaves the old, smaller buffer)
 	launch_integrate_forces(*this, dt);
 	launch_validate(*this, 2, 0);
 	launch_collision_events(*this, numPairs);              // :1284 (handleCollisionCallbacks: after the force integration)
@@ -1069,7 +1069,7 @@ struct mi_world { World w; mi_world(int dev) : w(dev) {} };
 
 namespace
 {
-	const uint32_t SNAPSHOT_MAGIC = 0x4850494Du, SNAPSHOT_VERSION = 4;
+	const uint32_t SNAPSHOT_MAGIC = 0x4850494Du, SNAPSHOT_VERSION = 5;
 	struct BlobWriter
 	{
 		std::vector<uint8_t> bytes;
@@ -1116,6 +1116,12 @@ namespace
 		for (const World::HCollider& c : w.colliders) out.pod(c);
 		for (const World::HHull& h : w.hulls) { out.vec(h.vertices); out.vec(h.triangles); out.put(h.aabbMin, 12); out.put(h.aabbMax, 12); }
 		for (const JointSet& js : w.joints) { out.vec(js.pods); out.vec(js.a); out.vec(js.b); out.vec(js.alive); }
+		// the sweep's sorting axis of the next step (the reference keeps it in its sap_context, collision_broad.cpp:20-24): it orients equal-type pairs
+		{
+			uint32_t axis = 0;
+			if (w.dCounters.p) { MI_CHECK(hipMemcpyAsync(&axis, w.dCounters.p + CTR_SAP_AXIS + (w.stats.numInternalSteps & 1u), sizeof(u32), hipMemcpyDeviceToHost, w.stream)); MI_CHECK(hipStreamSynchronize(w.stream)); }
+			out.pod(axis);
+		}
 		// force fields, triggers, and the previous step's overlap / collision sets (so that the next step raises the same events)
 		out.vec(w.fields); out.vec(w.triggers);
 		uint32_t flags = (w.collisionBeginEvents ? 1u : 0u) | (w.collisionEndEvents ? 2u : 0u); out.pod(flags);
@@ -1198,6 +1204,10 @@ mi_world* mi_world_restore(const mi_world_desc* desc, const void* buffer, uint64
 	for (uint64_t i = 0; in.ok && i < nc; ++i) { World::HCollider c; in.pod(c); w.colliders.push_back(c); }
 	for (uint64_t i = 0; in.ok && i < nh; ++i) { World::HHull h; in.vec(h.vertices); in.vec(h.triangles); in.get(h.aabbMin, 12); in.get(h.aabbMax, 12); w.hulls.push_back(h); }
 	for (JointSet& js : w.joints) { in.vec(js.pods); in.vec(js.a); in.vec(js.b); in.vec(js.alive); }
+	{
+		uint32_t axis = 0; in.pod(axis);
+		if (in.ok && axis < 3u && w.dCounters.p) { MI_CHECK(hipMemcpyAsync(w.dCounters.p + CTR_SAP_AXIS, &axis, sizeof(u32), hipMemcpyHostToDevice, w.stream)); MI_CHECK(hipStreamSynchronize(w.stream)); } // the restored world's step 0 reads word 0
+	}
 	std::vector<u64> triggerKeys, collisionKeys; uint32_t flags = 0;
 	in.vec(w.fields); in.vec(w.triggers); in.pod(flags); in.vec(triggerKeys); in.vec(collisionKeys);
 	in.pod(w.terrainChunksPerDim); in.pod(w.terrainChunkSize); in.pod(w.terrainAmplitude); in.get(w.terrainMinCorner, 12); in.get(w.terrainMaterial, 12);
@@ -2251,6 +2261,16 @@ int mi_debug_read_manifolds(mi_world* world, uint32_t* outPairs2, uint32_t* outC
 	}
 	return W->lastError;
 }
+// out[0] = sorting axis the last step oriented its equal-type pairs by, out[1] = the axis the next step will use (collision_broad.cpp:443-444)
+int mi_debug_sorting_axis(mi_world* world, uint32_t out[2])
+{
+	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
+	u32 words[2] = { 0, 0 };
+	d2h(W, words, W->dCounters.p + CTR_SAP_AXIS, sizeof(words));
+	const u32 k = W->stats.numInternalSteps;
+	out[0] = k ? words[(k - 1u) & 1u] : 0u; out[1] = words[k & 1u];
+	return W->lastError;
+}
 uint32_t mi_debug_num_colors(mi_world* world) { CHECK_WORLD(0); return MI_MAX_COLORS + 1; }
 int mi_debug_read_schedule(mi_world* world, uint32_t* outManifoldSlots, uint32_t* outColorStart)
 {
@@ -2304,7 +2324,7 @@ int mi_debug_flow_trace(mi_world* world, int enable, unsigned long long* out, ui
 {
 	CHECK_WORLD(MI_ERR_INVALID_ARGUMENT);
 	const size_t rows = (size_t)CL_MAX_TASKS * 16u;
-	if (enable && !W->flowTrace.p) { W->flowTrace.ensure(rows * 32, W->stream); MI_CHECK(hipMemsetAsync(W->flowTrace.p, 0, sizeof(u64) * rows * 32, W->stream)); }
+	if (enable && !W->flowTrace.p) { W->flowTrace.ensure(rows * 32, W->stream); if (!W->flowTrace.p) return W->lastError; MI_CHECK(hipMemsetAsync(W->flowTrace.p, 0, sizeof(u64) * rows * 32, W->stream)); }
 	if (out && W->flowTrace.p) d2h(W, out, W->flowTrace.p, sizeof(u64) * 32 * std::min<size_t>(numSlots, rows));
 	if (!enable) W->flowTrace.release();
 	return W->lastError;

@@ -695,6 +695,20 @@ def c4_ragdolls(n=256, pitch=3.0, hip_y=1.25):
     return s
 
 
+def c4_heap(side=8, layers=2, pitch=0.8, hip_y=1.25, layer_height=2.0):
+    """Ragdolls packed at `pitch` (closer than their arm span) in `layers` layers and dropped into a heap: islands of different cluster
+    tasks touch, so contacts between jointed bodies of different tasks are cut into the later phases and jointed bodies are handed
+    between phases.  Alternate ragdolls are turned by 90 degrees so that the spawn is not one block of overlapping arms."""
+    s = Scene("c4_heap_%dx%dx%d" % (side, side, layers), dt=1.0 / 60.0)
+    _ground(s, side * pitch * 0.5 + 20.0, material=(0.1, 1.0, 1.0))
+    for l in range(layers):
+        for i in range(side * side):
+            x = (i % side - 0.5 * (side - 1)) * pitch
+            z = (i // side - 0.5 * (side - 1)) * pitch
+            add_ragdoll(s, (x + 0.13 * l, hip_y + layer_height * l, z - 0.07 * l), yaw=0.5 * math.pi * ((i % side + i // side + l) % 2))
+    return s
+
+
 def joints_mix():
     """Every joint kind the BASELINE configs leave out, on the ground so that contacts and joints meet in one solve: two hanging
     chains held by DISTANCE joints (one added from global points, one from local points, each from a kinematic anchor), a chain of
@@ -791,6 +805,8 @@ def by_name(name):
         return c4_ragdolls()
     if name == "c4_small":
         return c4_ragdolls(4)
+    if name == "c4_heap":
+        return c4_heap()
     if name == "c5":
         return c3_mixed(1000000, area=700.0)
     if name == "c3_mid":

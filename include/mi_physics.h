@@ -258,6 +258,10 @@ int mi_slab_read_codes(mi_world* w, uint8_t* outCodes, uint32_t n);
 /* ---- inspection of the last internal step (parity tests; mirrors the arrays of physics.cpp:1207-1228) ---------------- */
 uint32_t mi_debug_num_pairs(mi_world* w);
 int mi_debug_read_pairs(mi_world* w, uint32_t* outPairs2);                              /* broadphase overlaps, (A,B) collider indices */
+/* sap_context::sortingAxis (collision_broad.cpp:20-24, 443-444): out[0] = the axis the last step's sweep order refers to (it orients
+ * equal-type pairs: A = the collider whose box starts first on it, collision_broad.cpp:127 + collision_narrow.cpp:2374), out[1] = the
+ * axis of largest AABB-centre variance of the last step = the next step's axis. */
+int mi_debug_sorting_axis(mi_world* w, uint32_t out[2]);
 int mi_debug_read_world_colliders(mi_world* w, void* outColliders64, float* outAabbs6); /* worldSpaceColliders / worldSpaceAABBs */
 uint32_t mi_debug_num_manifold_slots(mi_world* w);
 /* Per candidate pair after prune/classify/bucket (collision_narrow.cpp:2346-2453): ordered collider pair, contact count, and up to 4

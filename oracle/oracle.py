@@ -372,6 +372,16 @@ class OracleWorld:
     def sorting_axis(self):
         return self.lib.orc_sorting_axis_used(self.w), self.lib.orc_sorting_axis_next(self.w)
 
+    def set_sorting_axis(self, axis):
+        """sap_context::sortingAxis of the next broadphase (a world taking over another world's state mid-run)."""
+        self.lib.orc_set_sorting_axis(self.w, C.c_uint32(int(axis)))
+
+    def sorting_variance(self):
+        """Variance of the last broadphase's AABB centres per axis (float, summed collider after collider as the reference does)."""
+        out = np.zeros(3, np.float32)
+        self.lib.orc_sorting_variance(self.w, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
 
 # ---- stage-level functions ---------------------------------------------------------------------------------
 def narrowphase_ordered(colliders, pairs):

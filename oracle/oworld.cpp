@@ -95,6 +95,7 @@ struct world
 	// sap_context (collision_broad.cpp:20-24)
 	std::vector<sap_endpoint> endpoints;
 	u32 sortingAxis = 0;
+	float lastVariance[3] = { 0.f, 0.f, 0.f }; // of the last broadphase's AABB centres (the next axis is their argmax): tests look at near ties
 
 	// Per-step arrays kept for inspection by tests.
 	std::vector<bounding_box> worldSpaceAABBs;
@@ -437,6 +438,7 @@ static void broadphase(world& w)
 		}
 	}
 	vec3 variance = s2 - s * s / (float)numColliders;
+	w.lastVariance[0] = variance.x; w.lastVariance[1] = variance.y; w.lastVariance[2] = variance.z;
 	w.sortingAxis = (variance.x > variance.y) ? ((variance.x > variance.z) ? 0 : 2) : ((variance.y > variance.z) ? 1 : 2);
 }
 
@@ -1486,6 +1488,8 @@ u32 orc_num_contacts(world* w) { return (u32)w->contacts.size(); }
 u32 orc_num_collisions(world* w) { return (u32)w->collidingPairs.size(); }
 u32 orc_sorting_axis_used(world* w) { return w->usedSortingAxis; }
 u32 orc_sorting_axis_next(world* w) { return w->sortingAxis; }
+void orc_set_sorting_axis(world* w, u32 axis) { if (axis < 3u) w->sortingAxis = axis; } // a world that takes over another's state mid-run takes its sap_context::sortingAxis too
+void orc_sorting_variance(world* w, float* out3) { for (int k = 0; k < 3; ++k) out3[k] = w->lastVariance[k]; }
 
 // which: 0 = interpolated transform, 1 = physics_transform1, 2 = physics_transform0
 void orc_read_transforms(world* w, u32 which, float* out7)

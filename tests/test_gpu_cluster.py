@@ -35,7 +35,9 @@ def _follow(mi, oracle, scene, steps, check_from=0, own_every=0, **env):
         r = follow_step(g, o, scene.dt, 30, own_narrowphase=bool(own_every) and i % own_every == 0)
         assert r["pairs_equal"], "step %d: broadphase pair set differs" % i
         assert r["counts_equal"], "step %d: contact counts differ" % i
-        if "own_colliding_equal" in r:
+        assert r["axis_equal"] or r["axis_near_tie"], "step %d: sorting axis differs from the reference's" % i
+        assert r["orient_bad"] == 0 or not r["axis_equal"], "step %d: %d candidate pairs not in the reference's A/B order" % (i, r["orient_bad"])
+        if "own_colliding_equal" in r and r["axis_equal"]:
             assert r["own_colliding_equal"] and r["own_contacts"] == r["device_contacts"], "step %d own narrowphase: missing on device %d, extra on device %d, contacts %d vs %d" % (
                 i, r["own_missing_on_device"], r["own_extra_on_device"], r["own_contacts"], r["device_contacts"])
         worst = max(worst, r["vel_err"])
@@ -152,18 +154,21 @@ def test_cluster_follow_c3_full_size(mi, oracle):
         g.step_internal(scene.dt)
     o = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_CUSTOM))
     o.write_state(g.transforms(1), g.velocities())
+    o.set_sorting_axis(g.sorting_axis()[1])   # the oracle takes over mid-run: also the sweep's current sorting axis
     for i in range(3):
-        r = follow_step(g, o, scene.dt, 30, own_narrowphase=(i == 0))
+        r = follow_step(g, o, scene.dt, 30, own_narrowphase=True)
         assert r["pairs_equal"], "step %d: broadphase pair set differs (%d pairs)" % (i, r["num_pairs"])
         assert r["counts_equal"], "step %d: contact counts differ" % i
-        if i == 0:
+        assert r["axis_equal"] or r["axis_near_tie"], "step %d: sorting axis differs from the reference's" % i
+        if r["axis_equal"]:
+            assert r["orient_bad"] == 0, "step %d: %d candidate pairs not in the reference's A/B order" % (i, r["orient_bad"])
             assert r["own_colliding_equal"] and r["own_contacts"] == r["device_contacts"], "own narrowphase: missing on device %d, extra on device %d, contacts %d vs %d" % (
                 r["own_missing_on_device"], r["own_extra_on_device"], r["own_contacts"], r["device_contacts"])
         assert r["vel_err"] <= 1e-4 * max(1.0, r["vel_scale"]), "step %d: velocity error %g" % (i, r["vel_err"])
         assert r["pos_err"] <= 1e-4
     st = g.stats()
     assert st["numFlowRecoveries"] == 0 and st["clusterTasks"][0] >= 100, st
-    print("c3 full size:", {k: r[k] for k in ("num_pairs", "num_manifolds", "num_contacts", "vel_err", "pos_err")}, "tasks", st["clusterTasks"])
+    print("c3 full size:", {k: r[k] for k in ("num_pairs", "num_manifolds", "num_contacts", "vel_err", "pos_err", "orient_bad", "orient_ties", "own_start_ties", "own_missing_on_device", "own_extra_on_device")}, "tasks", st["clusterTasks"])
 
 
 def test_follow_c5_full_size_on_one_gpu(mi, oracle):
@@ -177,6 +182,7 @@ def test_follow_c5_full_size_on_one_gpu(mi, oracle):
     for _ in range(6):
         g.step_internal(scene.dt)
     o = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_CUSTOM))
+    o.set_sorting_axis(g.sorting_axis()[1])   # (before the presort: it orders the endpoints on that axis)
     o.write_state(g.transforms(1), g.velocities(), presort=True)
     for i in range(2):
         r = follow_step(g, o, scene.dt, 30)

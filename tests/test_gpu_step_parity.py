@@ -62,6 +62,43 @@ def test_follow_ragdolls_per_step(mi, oracle):
     _run(mi, oracle, scenes.by_name("c4_small"), 120, resync=True, vel_tol=1e-4, pos_tol=1e-4)
 
 
+def _run_multi_task_joints(mi, oracle, scene, steps, min_tasks, need_later_phase):
+    """Per-step follow of a jointed world large enough for SEVERAL cluster tasks: the island -> task assignment (k_cl_joint_weights /
+    _assign / _scatter on the refresh steps, k_cl_joint_assign_cached in between), the joint offsets of the tasks behind the first,
+    contacts between islands of different tasks (cut into the later phases), jointed bodies handed between phases."""
+    g, o = _worlds(mi, oracle, scene)
+    jc = _joint_counts(scene)
+    most_tasks, later_steps, worst_v, worst_p = 0, 0, 0.0, 0.0
+    for i in range(steps):
+        r = follow_step(g, o, scene.dt, 30, jc, resync=True)
+        assert r["pairs_equal"], "step %d: broadphase pair set differs" % i
+        assert r["counts_equal"], "step %d: contact counts differ" % i
+        assert r["vel_err"] <= 1e-4 * max(1.0, r["vel_scale"]), "step %d: velocity error %g (scale %g)" % (i, r["vel_err"], r["vel_scale"])
+        assert r["pos_err"] <= 1e-4 and r["rot_err"] <= 1e-4, "step %d: pose error %g / %g" % (i, r["pos_err"], r["rot_err"])
+        st = g.stats()
+        assert st["numFlowRecoveries"] == 0, "step %d: the cluster sweep gave up" % i
+        most_tasks = max(most_tasks, st["clusterTasks"][0]); later_steps += sum(st["clusterTasks"][1:]) > 0
+        worst_v = max(worst_v, r["vel_err"]); worst_p = max(worst_p, r["pos_err"])
+    print(scene.name, "per-step follow over", steps, "steps: worst velocity error %.2e, pose error %.2e; most first-phase tasks %d, steps with later-phase tasks %d; last step: tasks %s manifolds %s contacts %s"
+          % (worst_v, worst_p, most_tasks, later_steps, st["clusterTasks"], st["clusterManifolds"], r.get("num_contacts")))
+    assert most_tasks >= min_tasks, "the world ran in %d first-phase tasks only" % most_tasks
+    if need_later_phase:
+        assert later_steps >= steps // 4, "islands of different tasks hardly ever touched (%d of %d steps)" % (later_steps, steps)
+
+
+def test_follow_c4_full_size_per_step(mi, oracle):
+    """BASELINE config 4 at its full size: 256 ragdolls (3 584 bodies, 3 328 joints) — the cluster sweep spreads the islands over
+    ~20 tasks, the benchmark's own path for --workload c4 — per step from identical inputs, 1e-4."""
+    from directx_renderer_kurth_amd import scenes
+    _run_multi_task_joints(mi, oracle, scenes.by_name("c4"), 60, min_tasks=16, need_later_phase=False)
+
+
+def test_follow_ragdoll_heap_per_step(mi, oracle):
+    """128 ragdolls packed closer than their arm span, in two layers, dropped into a heap: islands of different tasks touch."""
+    from directx_renderer_kurth_amd import scenes
+    _run_multi_task_joints(mi, oracle, scenes.by_name("c4_heap"), 90, min_tasks=4, need_later_phase=True)
+
+
 def test_follow_joints_mix_per_step(mi, oracle):
     """The joint kinds and add variants the BASELINE configs leave out, per step from identical inputs: distance joints (device
     kernels k_distance_init / k_distance_solve; constraints.cpp:189-264) added from global and from local points, ball joints from
