@@ -32,12 +32,14 @@ void prim_exclusive_scan_u32(World& w, const u32* in, u32* out, u32 n);
 #define CL_LANES 1024u                    // k_cl_color
 #define CL_TASKS_PER_PHASE 2u              // tasks of one phase a workgroup may run (LDS holds the bodies and meta of all its tasks)
 #define CL_MAX_LOCAL_TASKS 8u              // tasks of all phases per workgroup
-#define CL_WEIGHT_REG_LIMIT (64u * 1250u)  // chunk weight up to which a task's manifolds (almost always) fit two per lane
-#define CLS_LANES 512u                    // k_cl_solve: 8 waves, so that a lane may keep ...
-#define CLS_R 2u                          // ... the first contact row of this many manifolds in registers (256 VGPRs per lane at 2 waves per SIMD)
+#define CLS_LANES 512u                    // k_cl_solve: 8 waves = 128 quads (four lanes work on one contact row) ...
+#define CLQ_QUADS (CLS_LANES / 4u)
+#define CLQ_SETS 10u                      // ... each keeping this many contact rows in registers (19 VGPRs per row and lane; 256 VGPRs per lane at 2 waves per SIMD)
+#define CLQ_REG_CONTACTS (CLQ_QUADS * CLQ_SETS) // contacts of a workgroup's first task that live in registers
+#define CL_WEIGHT_REG_LIMIT (64u * (CLQ_REG_CONTACTS - 30u))  // chunk weight up to which a task's contacts (almost always) fit the register sets
 #define CL_UNASSIGNED 0xFFFFFFFFu
 #define CL_WEIGHT_MANIFOLD 64u            // weight of a manifold on the curve ...
-#define CL_WEIGHT_EXTRA 48u               // ... plus this per contact beyond the first (they cost LDS rows)
+#define CL_WEIGHT_EXTRA 64u               // ... plus this per contact beyond the first (the sweep's unit is the contact)
 #define CL_TASK_MAX_MANIFOLDS 2048u       // hard limits of k_cl_color's LDS tables (a task normally holds <= taskManifolds + one body's degree)
 #define CL_TASK_MAX_BODIES 4095u
 #define CL_HASH_SIZE 8192u
@@ -434,8 +436,8 @@ __global__ void __launch_bounds__(256) k_cl_scatter(const u32* __restrict__ coun
 // ---------------------------------------------------------------------------------------------------------------
 struct ClTask
 {
-	u32 first, count, numBodies, numShared, numColors, serialStart, numRows, sharedBase; // sharedBase: first hand-over record of the task's shared bodies
-	u32 colorStart[72]; // position (relative to first) of the first manifold of colour c; [numColors] = serialStart
+	u32 first, count, numBodies, numShared, numColors, serialStart, numRows, sharedBase; // numRows: contacts; serialStart: first CONTACT position of the serial tail; sharedBase: first hand-over record of the task's shared bodies
+	u32 colorStart[72]; // CONTACT position (relative to 4 * first in the contact tables) of the first contact of colour c; [numColors] = serialStart
 };
 static_assert(sizeof(ClTask) == 320, "task header");
 
@@ -677,12 +679,20 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 				u32 la = rAB[r] & 0xFFFFu, lb = rAB[r] >> 16;
 				bool won = (la == CL_LOCAL_STATIC || claim[la] == bid[r]) && (lb == CL_LOCAL_STATIC || claim[lb] == bid[r]);
 				if (!won && !lastRound) { ++left; continue; }
+				// A manifold of cnt contacts takes cnt CONSECUTIVE colours [c, c + cnt) on both bodies (the sweep's step is one contact row:
+				// its contacts run in colours c, c + 1, ...), the lowest such run free on both: manifolds that share a body get disjoint
+				// runs, so "by first colour" is still a sequential order of whole manifolds (what the schedule export reports).
 				u64 used = (la != CL_LOCAL_STATIC ? mask[la] : 0ull) | (lb != CL_LOCAL_STATIC ? mask[lb] : 0ull);
-				u32 c = (won && ~used) ? (u32)__ffsll((long long)~used) - 1u : CL_SERIAL_COLOR;
+				u64 fr = ~used;
+				if (cnt > 1u) fr &= fr >> 1;
+				if (cnt > 2u) fr &= fr >> 1;
+				if (cnt > 3u) fr &= fr >> 1; // bit c set = colours c .. c + cnt - 1 all free (the shifts bring zeros in at the top: a run never passes colour 63)
+				u32 c = (won && fr) ? (u32)__ffsll((long long)fr) - 1u : CL_SERIAL_COLOR;
 				if (c < CL_SERIAL_COLOR)
 				{
-					if (la != CL_LOCAL_STATIC) mask[la] |= 1ull << c; // the only winner on this body in this round
-					if (lb != CL_LOCAL_STATIC) mask[lb] |= 1ull << c;
+					const u64 run = ((cnt >= 64u ? 0ull : (1ull << cnt)) - 1ull) << c;
+					if (la != CL_LOCAL_STATIC) mask[la] |= run; // the only winner on this body in this round
+					if (lb != CL_LOCAL_STATIC) mask[lb] |= run;
 				}
 				rKey[r] = c * 4u + (4u - cnt);
 			}

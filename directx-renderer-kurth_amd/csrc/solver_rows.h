@@ -28,24 +28,33 @@ MI_DEV void loadRow(ContactRow& r, u32 k, u32 s, size_t rowCap, const float4* __
 	r.lam = rowLambda[(size_t)k * rowCap + s];
 }
 
-// J v for direction d with angular parts cA = rA x d, cB = rB x d.
+// Quad form.  The cluster sweep solves a row with FOUR lanes, one per body vector (vA, wA, vB, wB), so the row velocity is the sum of
+// four 3-term partial dots, each accumulated z, y, x with fused multiply-adds and combined as (pA_lin + pA_ang) + (pB_lin + pB_ang)
+// with body A's terms negated in the operands; the impulse delta d is applied as x = fma(d, a, x) with the "apply vectors"
+// a = -(invMassA * dir), -JA, invMassB * dir, JB.  Every solver path (this scalar-lane restatement, the quad lanes of k_cluster.hip)
+// evaluates exactly this expression tree, and so does the oracle (oracle/oconstraints.h: solveCollisionConstraintRowForm).
+MI_DEV float rowDot3(V3 x, V3 d) { float s = x.z * d.z; s = __builtin_fmaf(x.y, d.y, s); return __builtin_fmaf(x.x, d.x, s); }
 MI_DEV float rowVelocity(V3 d, V3 cA, V3 cB, V3 vA, V3 wA, V3 vB, V3 wB)
 {
-	V3 dv = vB - vA;
-	float s = dv.z * d.z;
-	s = __builtin_fmaf(dv.y, d.y, s); s = __builtin_fmaf(dv.x, d.x, s);
-	s = __builtin_fmaf(wB.z, cB.z, s); s = __builtin_fmaf(wB.y, cB.y, s); s = __builtin_fmaf(wB.x, cB.x, s);
-	s = __builtin_fmaf(-wA.z, cA.z, s); s = __builtin_fmaf(-wA.y, cA.y, s); s = __builtin_fmaf(-wA.x, cA.x, s);
-	return s;
+	return (rowDot3(vA, -d) + rowDot3(wA, -cA)) + (rowDot3(vB, d) + rowDot3(wB, cB));
 }
-// v -+= invMass * lambda * d, w -+= J * lambda
+MI_DEV V3 rowFma(float d, V3 a, V3 x) { return v3(__builtin_fmaf(d, a.x, x.x), __builtin_fmaf(d, a.y, x.y), __builtin_fmaf(d, a.z, x.z)); }
+// v -+= (invMass * dir) * lambda, w -+= J * lambda
 MI_DEV void rowApply(float lambda, V3 d, V3 JA, V3 JB, float invMassA, float invMassB, V3& vA, V3& wA, V3& vB, V3& wB)
 {
-	float a = invMassA * lambda, b = invMassB * lambda;
-	vA = v3(__builtin_fmaf(-a, d.x, vA.x), __builtin_fmaf(-a, d.y, vA.y), __builtin_fmaf(-a, d.z, vA.z));
-	vB = v3(__builtin_fmaf(b, d.x, vB.x), __builtin_fmaf(b, d.y, vB.y), __builtin_fmaf(b, d.z, vB.z));
-	wA = v3(__builtin_fmaf(-lambda, JA.x, wA.x), __builtin_fmaf(-lambda, JA.y, wA.y), __builtin_fmaf(-lambda, JA.z, wA.z));
-	wB = v3(__builtin_fmaf(lambda, JB.x, wB.x), __builtin_fmaf(lambda, JB.y, wB.y), __builtin_fmaf(lambda, JB.z, wB.z));
+	vA = rowFma(lambda, -(invMassA * d), vA);
+	wA = rowFma(lambda, -JA, wA);
+	vB = rowFma(lambda, invMassB * d, vB);
+	wB = rowFma(lambda, JB, wB);
+}
+// clamp(x, -m, m) for m >= 0 (median of three: one instruction on the device; the oracle's clampf gives the same value for every non-NaN input)
+MI_DEV float rowClampSym(float x, float m)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_amdgcn_fmed3f(x, -m, m);
+#else
+	return x < -m ? -m : (x > m ? m : x);
+#endif
 }
 
 MI_DEV void solveRow(ContactRow& r, V3 n, float friction, float invMassA, float invMassB, V3& vA, V3& wA, V3& vB, V3& wB)
@@ -57,18 +66,16 @@ MI_DEV void solveRow(ContactRow& r, V3 n, float friction, float invMassA, float 
 	float impulseN = r.lam.x, impulseT = r.lam.y;
 	{ // tangent (constraints.cpp:3404-3424)
 		float vt = rowVelocity(t, cAt, cBt, vA, wA, vB, wB);
-		float lambda = -mT * vt;
 		float maxFriction = friction * impulseN;
-		float newImpulse = clampf(impulseT + lambda, -maxFriction, maxFriction);
-		lambda = newImpulse - impulseT;
+		float newImpulse = rowClampSym(__builtin_fmaf(-mT, vt, impulseT), maxFriction);
+		float lambda = newImpulse - impulseT;
 		impulseT = newImpulse;
 		rowApply(lambda, t, JtA, JtB, invMassA, invMassB, vA, wA, vB, wB);
 	}
 	{ // normal (constraints.cpp:3426-3442)
 		float vn = rowVelocity(n, cAn, cBn, vA, wA, vB, wB);
-		float lambda = -mN * (vn - bias);
-		float impulse = fmaxf(impulseN + lambda, 0.f);
-		lambda = impulse - impulseN;
+		float impulse = fmaxf(__builtin_fmaf(-mN, vn - bias, impulseN), 0.f);
+		float lambda = impulse - impulseN;
 		impulseN = impulse;
 		rowApply(lambda, n, JnA, JnB, invMassA, invMassB, vA, wA, vB, wB);
 	}

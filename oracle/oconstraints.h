@@ -249,25 +249,23 @@ static inline void solveCollisionConstraint(collision_constraint& constraint, co
 // The same contact in ROW FORM, as the device evaluates it (directx-renderer-kurth_amd/csrc/solver_rows.h): the relative anchor velocity
 // projected on the row direction d, dot((vB + wB x rB) - (vA + wA x rA), d), is written with the scalar triple product as
 // d . (vB - vA) + (rB x d) . wB - (rA x d) . wA and evaluated with fused multiply-adds in the association of the reference's wide
-// dot (fmadd(a.x, b.x, fmadd(a.y, b.y, a.z * b.z)), core/math_simd.h:241); the impulse is applied as v -+= (invMass * lambda) * d,
-// w -+= J * lambda, one fma per component.  Same mathematics as solveCollisionConstraint above, different rounding: this is the
+// dot (fmadd(a.x, b.x, fmadd(a.y, b.y, a.z * b.z)), core/math_simd.h:241) per body vector; the impulse is applied as
+// v -+= lambda * (invMass * d), w -+= lambda * J, one fma per component.  Same mathematics as solveCollisionConstraint above, different rounding: this is the
 // function the device is compared with bit for bit; tests/test_oracle.py bounds its distance from the reference formula.
+// (quad form: four 3-term partial dots, one per body vector, each accumulated z, y, x with fused multiply-adds, body A's negated in the
+// operands, combined as (pA_lin + pA_ang) + (pB_lin + pB_ang) — the device's four lanes per row and their two in-quad adds)
+static inline float rowDot3(vec3 x, vec3 d) { float s = x.z * d.z; s = __builtin_fmaf(x.y, d.y, s); return __builtin_fmaf(x.x, d.x, s); }
 static inline float rowVelocity(vec3 d, vec3 cA, vec3 cB, vec3 vA, vec3 wA, vec3 vB, vec3 wB)
 {
-	vec3 dv = vB - vA;
-	float s = dv.z * d.z;
-	s = __builtin_fmaf(dv.y, d.y, s); s = __builtin_fmaf(dv.x, d.x, s);
-	s = __builtin_fmaf(wB.z, cB.z, s); s = __builtin_fmaf(wB.y, cB.y, s); s = __builtin_fmaf(wB.x, cB.x, s);
-	s = __builtin_fmaf(-wA.z, cA.z, s); s = __builtin_fmaf(-wA.y, cA.y, s); s = __builtin_fmaf(-wA.x, cA.x, s);
-	return s;
+	return (rowDot3(vA, -d) + rowDot3(wA, -cA)) + (rowDot3(vB, d) + rowDot3(wB, cB));
 }
+static inline vec3 rowFma(float d, vec3 a, vec3 x) { return vec3(__builtin_fmaf(d, a.x, x.x), __builtin_fmaf(d, a.y, x.y), __builtin_fmaf(d, a.z, x.z)); }
 static inline void rowApply(float lambda, vec3 d, vec3 JA, vec3 JB, float invMassA, float invMassB, vec3& vA, vec3& wA, vec3& vB, vec3& wB)
 {
-	float a = invMassA * lambda, b = invMassB * lambda;
-	vA = vec3(__builtin_fmaf(-a, d.x, vA.x), __builtin_fmaf(-a, d.y, vA.y), __builtin_fmaf(-a, d.z, vA.z));
-	vB = vec3(__builtin_fmaf(b, d.x, vB.x), __builtin_fmaf(b, d.y, vB.y), __builtin_fmaf(b, d.z, vB.z));
-	wA = vec3(__builtin_fmaf(-lambda, JA.x, wA.x), __builtin_fmaf(-lambda, JA.y, wA.y), __builtin_fmaf(-lambda, JA.z, wA.z));
-	wB = vec3(__builtin_fmaf(lambda, JB.x, wB.x), __builtin_fmaf(lambda, JB.y, wB.y), __builtin_fmaf(lambda, JB.z, wB.z));
+	vA = rowFma(lambda, -(invMassA * d), vA);
+	wA = rowFma(lambda, -JA, wA);
+	vB = rowFma(lambda, invMassB * d, vB);
+	wB = rowFma(lambda, JB, wB);
 }
 static inline void solveCollisionConstraintRowForm(collision_constraint& constraint, const collision_contact& contact, constraint_body_pair pair, rigid_body_global_state* rbs)
 {
@@ -276,19 +274,17 @@ static inline void solveCollisionConstraintRowForm(collision_constraint& constra
 	vec3 vA = rbA.linearVelocity, wA = rbA.angularVelocity, vB = rbB.linearVelocity, wB = rbB.angularVelocity;
 	{
 		float vt = rowVelocity(constraint.tangent, constraint.crAt, constraint.crBt, vA, wA, vB, wB);
-		float lambda = -constraint.effectiveMassInTangentDir * vt;
 		float friction = (float)(contact.friction_restitution >> 16) / (float)0xFFFF;
 		float maxFriction = friction * constraint.impulseInNormalDir;
-		float newImpulse = clampf(constraint.impulseInTangentDir + lambda, -maxFriction, maxFriction);
-		lambda = newImpulse - constraint.impulseInTangentDir;
+		float newImpulse = clampf(__builtin_fmaf(-constraint.effectiveMassInTangentDir, vt, constraint.impulseInTangentDir), -maxFriction, maxFriction);
+		float lambda = newImpulse - constraint.impulseInTangentDir;
 		constraint.impulseInTangentDir = newImpulse;
 		rowApply(lambda, constraint.tangent, constraint.tangentImpulseToAngularVelocityA, constraint.tangentImpulseToAngularVelocityB, rbA.invMass, rbB.invMass, vA, wA, vB, wB);
 	}
 	{
 		float vn = rowVelocity(contact.normal, constraint.crAn, constraint.crBn, vA, wA, vB, wB);
-		float lambda = -constraint.effectiveMassInNormalDir * (vn - constraint.bias);
-		float impulse = std::max(constraint.impulseInNormalDir + lambda, 0.f);
-		lambda = impulse - constraint.impulseInNormalDir;
+		float impulse = std::max(__builtin_fmaf(-constraint.effectiveMassInNormalDir, vn - constraint.bias, constraint.impulseInNormalDir), 0.f);
+		float lambda = impulse - constraint.impulseInNormalDir;
 		constraint.impulseInNormalDir = impulse;
 		rowApply(lambda, contact.normal, constraint.normalImpulseToAngularVelocityA, constraint.normalImpulseToAngularVelocityB, rbA.invMass, rbB.invMass, vA, wA, vB, wB);
 	}

@@ -39,15 +39,42 @@ MI_DEV void solveRow2(ContactRow& r, V3 n, float friction, float invMassA, float
 #ifdef ROW2
 #define solveRow(R_, N_, F_, MA_, MB_, VA_, WA_, VB_, WB_) solveRow2(R_, N_, F_, MA_, MB_, VA_, WA_, VB_, WB_, 0.013f)
 #endif
-enum { V_FULL = 0, V_NOBARRIER = 1, V_ALLWAVES = 2, V_BARRIER_ONLY = 3, V_LDS_ONLY = 4, V_NO_LDS = 5, V_FOUR = 6, V_FOUR_PREFETCH = 7, V_COUNT = 8 };
+enum { V_FULL = 0, V_NOBARRIER = 1, V_ALLWAVES = 2, V_BARRIER_ONLY = 3, V_LDS_ONLY = 4, V_NO_LDS = 5, V_FOUR = 6, V_FOUR_PREFETCH = 7, V_QUAD_ONE = 8, V_QUAD_ALL = 9, V_LDS_R = 10, V_LDS_W = 11, V_LDS_1 = 12, V_COUNT = 13 };
 static const char* names[V_COUNT] = { "full: one wave solves, 8 waves barrier", "same wave every step, wave fence instead of the barrier", "all 8 waves solve every step + barrier", "barrier only",
-	"LDS round trip + barrier, no arithmetic", "arithmetic + barrier, bodies stay in registers", "4-contact manifold: rows 1-3 from LDS one after the other", "4-contact manifold: all LDS rows requested up front" };
+	"LDS round trip + barrier, no arithmetic", "arithmetic + barrier, bodies stay in registers", "4-contact manifold: rows 1-3 from LDS one after the other", "4-contact manifold: all LDS rows requested up front",
+	"QUAD: 4 lanes per contact (one body vector each), one wave active", "QUAD: all 8 waves active", "LDS: 4 x read b128 + barrier", "LDS: 4 x write b128 + barrier", "LDS: 1 read + 1 write b128 + barrier" };
 
 MI_DEV void ldRow(ContactRow& r, const float4* lds, u32 off, u32 cap, u32 row)
 {
 	const float4* P = lds + off + row;
 	r.p0 = P[0]; r.p1 = P[cap]; r.p2 = P[2 * cap]; r.p3 = P[3 * cap]; r.p4 = P[4 * cap]; r.p5 = P[5 * cap]; r.p6 = P[6 * cap];
 	float4 q = P[7 * cap]; r.p7 = make_float2(q.x, q.y); r.lam = make_float2(q.z, q.w);
+}
+
+
+// QUAD candidate: four lanes per contact row.  Lane q owns one of the four body vectors x (vA, wA, vB, wB: one float4 of LDS) and
+// its pieces of the row: dT / dN (what its vector is dotted with, signs folded in), aT / aN (what an impulse adds to it, inverse
+// mass and signs folded in).  The row velocity is the sum of the four lanes' 3-term partial dots (two DPP adds inside the quad:
+// every lane gets the bit-identical total), the impulse update is done redundantly by the four lanes, each then updates its vector.
+struct QuadRow { V3 dT, aT, dN, aN; float mT, mN, bias, lamN, lamT; };
+MI_DEV float quadSum(float p)
+{
+	float q = p + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, false)); // quad_perm [1,0,3,2]
+	return q + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+}
+MI_DEV void solveQuad(QuadRow& r, float friction, V3& x)
+{
+	float pt = x.z * r.dT.z; pt = __builtin_fmaf(x.y, r.dT.y, pt); pt = __builtin_fmaf(x.x, r.dT.x, pt);
+	float vt = quadSum(pt);
+	float maxFriction = friction * r.lamN;
+	float newT = __builtin_amdgcn_fmed3f(__builtin_fmaf(-r.mT, vt, r.lamT), -maxFriction, maxFriction);
+	float d = newT - r.lamT; r.lamT = newT;
+	x = v3(__builtin_fmaf(d, r.aT.x, x.x), __builtin_fmaf(d, r.aT.y, x.y), __builtin_fmaf(d, r.aT.z, x.z));
+	float pn = x.z * r.dN.z; pn = __builtin_fmaf(x.y, r.dN.y, pn); pn = __builtin_fmaf(x.x, r.dN.x, pn);
+	float vn = quadSum(pn);
+	float newN = fmaxf(__builtin_fmaf(-r.mN, vn - r.bias, r.lamN), 0.f);
+	d = newN - r.lamN; r.lamN = newN;
+	x = v3(__builtin_fmaf(d, r.aN.x, x.x), __builtin_fmaf(d, r.aN.y, x.y), __builtin_fmaf(d, r.aN.z, x.z));
 }
 
 template <int VAR> __global__ void __launch_bounds__(512) k_step(int steps, unsigned long long* out, float4* sink)
@@ -63,13 +90,23 @@ template <int VAR> __global__ void __launch_bounds__(512) k_step(int steps, unsi
 	float4 sh = make_float4(0.f, 1.f, 0.f, 0.5f);
 	V3 n = v3(sh.x, sh.y, sh.z);
 	V3 kvA = v3(0.f, 0.f, 0.f), kwA = kvA, kvB = kvA, kwB = kvA; // V_NO_LDS: the bodies
+	QuadRow qr; qr.dT = v3(0.1f, 0.2f, 0.3f + 0.001f * tid); qr.aT = v3(0.3f, 0.1f, 0.2f); qr.dN = v3(0.f, 1.f, 0.01f * (tid & 3)); qr.aN = v3(0.1f, 0.5f, 0.2f); qr.mT = 0.6f; qr.mN = 0.7f; qr.bias = 0.01f; qr.lamN = 0.f; qr.lamT = 0.f;
+	const u32 qAddr = 2 * tid; // lane q of quad tid / 4: one float4 of the quad's two bodies
 	__syncthreads();
 	unsigned long long t0 = __builtin_amdgcn_s_memtime();
 	for (int s = 0; s < steps; ++s)
 	{
 		bool mine = (VAR == V_ALLWAVES) ? true : (VAR == V_NOBARRIER ? wave == 0 : wave == (u32)(s & 7));
 		if (VAR == V_BARRIER_ONLY) mine = false;
-		if (mine)
+		if (VAR == V_QUAD_ALL) mine = true;
+		if (VAR == V_QUAD_ONE || VAR == V_QUAD_ALL)
+		{
+			if (mine) { float4 b = lds[qAddr]; V3 x = v3f4(b); solveQuad(qr, sh.w, x); lds[qAddr] = make_float4(x.x, x.y, x.z, b.w); }
+		}
+		else if (VAR == V_LDS_R) { if (mine) { float4 a0 = lds[rdA], a1 = lds[rdA + 1], b0 = lds[rdB], b1 = lds[rdB + 1]; kvA.x += a0.x + a1.y + b0.z + b1.x; } }
+		else if (VAR == V_LDS_W) { if (mine) { float4 f = make_float4(kvA.x, kvA.y, 1.f, 2.f); lds[rdA] = f; lds[rdA + 1] = f; lds[rdB] = f; lds[rdB + 1] = f; } }
+		else if (VAR == V_LDS_1) { if (mine) { float4 b = lds[qAddr]; b.x += 1.f; lds[qAddr] = b; } }
+		else if (mine)
 		{
 			if (VAR == V_NO_LDS) solveRow(r, n, sh.w, 0.5f, 0.5f, kvA, kwA, kvB, kwB);
 			else
@@ -98,7 +135,7 @@ template <int VAR> __global__ void __launch_bounds__(512) k_step(int steps, unsi
 	}
 	unsigned long long t1 = __builtin_amdgcn_s_memtime();
 	if (tid == 0) out[blockIdx.x] = t1 - t0;
-	if (sink) { sink[blockIdx.x * 512 + tid] = make_float4(r.lam.x + kvA.x, r.lam.y + kwB.y, lds[rdA].x, lds[rdB + 1].y); }
+	if (sink) { sink[blockIdx.x * 512 + tid] = make_float4(r.lam.x + kvA.x + qr.lamN, r.lam.y + kwB.y + qr.lamT, lds[rdA].x, lds[rdB + 1].y); }
 }
 
 template <int VAR> static void run(int blocks, int steps, unsigned long long* dOut, float4* dSink)
@@ -125,6 +162,7 @@ int main(int argc, char** argv)
 	{
 		run<V_FULL>(blocks, steps, dOut, dSink); run<V_NOBARRIER>(blocks, steps, dOut, dSink); run<V_ALLWAVES>(blocks, steps, dOut, dSink); run<V_BARRIER_ONLY>(blocks, steps, dOut, dSink);
 		run<V_LDS_ONLY>(blocks, steps, dOut, dSink); run<V_NO_LDS>(blocks, steps, dOut, dSink); run<V_FOUR>(blocks, steps, dOut, dSink); run<V_FOUR_PREFETCH>(blocks, steps, dOut, dSink);
+		run<V_QUAD_ONE>(blocks, steps, dOut, dSink); run<V_QUAD_ALL>(blocks, steps, dOut, dSink); run<V_LDS_R>(blocks, steps, dOut, dSink); run<V_LDS_W>(blocks, steps, dOut, dSink); run<V_LDS_1>(blocks, steps, dOut, dSink);
 	}
 	return 0;
 }

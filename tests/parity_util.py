@@ -74,6 +74,7 @@ def orientation_check(gpu, orc_world, slots):
     the number of exact start ties (where the reference's order comes from its endpoint array's history; not judged)."""
     cols, aabbs = orc_world.world_colliders()
     sl = np.asarray(slots, np.int64).reshape(-1, 2)
+    sl = sl[(sl[:, 0] < len(cols)) & (sl[:, 1] < len(cols))]   # (terrain contacts have no collider pair)
     if not len(sl):
         return {"orient_bad": 0, "orient_ties": 0, "axis_equal": True}
     axis = orc_world.sorting_axis()[0]
