@@ -34,9 +34,10 @@ void prim_exclusive_scan_u32(World& w, const u32* in, u32* out, u32 n);
 #define CL_MAX_LOCAL_TASKS 8u              // tasks of all phases per workgroup
 #define CLS_LANES 512u                    // k_cl_solve: 8 waves = 128 quads (four lanes work on one contact row) ...
 #define CLQ_QUADS (CLS_LANES / 4u)
-#define CLQ_SETS 10u                      // ... each keeping this many contact rows in registers (19 VGPRs per row and lane; 256 VGPRs per lane at 2 waves per SIMD)
-#define CLQ_REG_CONTACTS (CLQ_QUADS * CLQ_SETS) // contacts of a workgroup's first task that live in registers
-#define CL_WEIGHT_REG_LIMIT (64u * (CLQ_REG_CONTACTS - 30u))  // chunk weight up to which a task's contacts (almost always) fit the register sets
+#define CLQ_SETS 8u                       // ... each keeping this many contact rows in registers (19 VGPRs per row and lane; 256 VGPRs per lane at 2 waves per SIMD)
+#define CLQ_REG_CONTACTS (CLQ_QUADS * CLQ_SETS) // contacts of a workgroup's first task that live in registers (worlds whose joints run inside the sweep: CLQ_SETS_JOINTS sets, the joint solves need the registers)
+#define CLQ_SETS_JOINTS 4u
+#define CL_WEIGHT_REG_LIMIT (64u * 1250u)  // chunk weight up to which a task's INTERIOR contacts (70 - 85 % of what its bodies own) fit the register sets, give or take what LDS holds
 #define CL_UNASSIGNED 0xFFFFFFFFu
 #define CL_WEIGHT_MANIFOLD 64u            // weight of a manifold on the curve ...
 #define CL_WEIGHT_EXTRA 64u               // ... plus this per contact beyond the first (the sweep's unit is the contact)
@@ -150,9 +151,11 @@ MI_DEV u32 clBid(u32 slot, u32 count, u32 round, u32 i) { return (((4u - count) 
 #define CL_SUBCOUNTERS 8u // a task's append cursor is split in 8 (by workgroup) so that ~650 returning atomics do not queue on one address
 
 // Everything the assignment accumulates into, cleared in one launch.
-__global__ void __launch_bounds__(256) k_cl_clear(u32 nb1, u32* __restrict__ wsum, u32* __restrict__ phaseMask, u32* __restrict__ taskCount, u32* __restrict__ jointCount, u32* __restrict__ counters)
+__global__ void __launch_bounds__(256) k_cl_clear(u32 nb1, u32* __restrict__ wsum, u32* __restrict__ phaseMask, u32* __restrict__ taskCount, u32* __restrict__ jointCount, u32* __restrict__ counters, u32* __restrict__ compLabel)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nb1) compLabel[i] = i;               // components of what the curve phases leave over: every body its own
+	if (i < 5u) counters[CTR_CL_LEFT + i] = 0;
 	if (i < CL_MAX_TASKS) jointCount[i] = 0;
 	if (i < CL_MAX_PARTS * nb1) wsum[i] = 0;
 	if (i < nb1) phaseMask[i] = 0;
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(256) k_cl_joint_scatter(u32 numJoints, const u
 // Phase p: assign what is interior; what is left adds its weight to the next phase's curve, or (last partition) goes to the rest task.
 __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 phase, u32 numParts, u32 taskWeight, u32 maxTasks, const uint4* __restrict__ actIds,
 	const u32* __restrict__ rank, const u32* __restrict__ cum, const u32* __restrict__ rankNext, u32* __restrict__ wsumNext,
-	u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask, u32* __restrict__ status, const u32* __restrict__ rep)
+	u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask, u32* __restrict__ status, const u32* __restrict__ rep, u32* __restrict__ leftList, u32 leftCap)
 {
 	u32 j = blockIdx.x * blockDim.x + threadIdx.x;
 	taskWeight = clEffectiveWeight(taskWeight, cum[nb], maxTasks);
@@ -238,8 +241,19 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 				if (ta >= CL_MAX_TASKS) { atomicOr(status, 1u); ta = CL_MAX_TASKS - 1u; }
 				key = phase * CL_MAX_TASKS + ta;
 			}
-			else if (phase + 1u == numParts) key = CL_MAX_PARTS * CL_MAX_TASKS; // the rest task
+			else if (phase + 1u == numParts && !leftList) key = CL_MAX_PARTS * CL_MAX_TASKS; // the rest task
 		}
+	}
+	// what the last curve phase leaves goes to the component phase (k_cl_components), through a list
+	const bool toList = pending && key == CL_UNASSIGNED && phase + 1u == numParts && leftList;
+	if (toList)
+	{
+		const u64 m = __ballot(1);
+		const u32 lane = threadIdx.x & 63u, leader = (u32)__ffsll((long long)m) - 1u;
+		u32 base = 0;
+		if (lane == leader) base = atomicAdd(&counters[CTR_CL_LEFT], (u32)__popcll(m));
+		base = __shfl(base, leader) + (u32)__popcll(m & ((1ull << lane) - 1ull));
+		if (base < leftCap) leftList[base] = j;
 	}
 	bool left = pending && key == CL_UNASSIGNED;
 	u32 numLeft = (u32)__syncthreads_count(left); // one atomic per workgroup
@@ -276,7 +290,7 @@ __global__ void __launch_bounds__(256) k_cl_assign(u32* counters, u32 nb, u32 ph
 		if (da && !(__hip_atomic_load(&phaseMask[ids.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << ph))) atomicOr(&phaseMask[ids.x], 1u << ph);
 		if (db && !(__hip_atomic_load(&phaseMask[ids.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << ph))) atomicOr(&phaseMask[ids.y], 1u << ph);
 	}
-	else
+	else if (!toList)
 	{
 		u32 ra = rankNext[ids.x], rb = rankNext[ids.y];
 		atomicAdd(&wsumNext[min(ra, rb)], clWeight(ids.z));
@@ -300,7 +314,7 @@ __global__ void __launch_bounds__(256) k_cl_store_chunks(u32 nb, u32 taskWeight,
 // the per-step pipeline on what is left, which keeps their tasks at the size their fast path needs).  What the cached phases leave
 // goes on to phase numCached (its weight onto that phase's curve), or to the rest task when there is none.
 __global__ void __launch_bounds__(256) k_cl_assign_cached(u32* counters, u32 nb, u32 numParts, u32 numCached, u32 withJoints, const uint4* __restrict__ actIds, const u32* __restrict__ chunk,
-	const u32* __restrict__ rankNext, u32* __restrict__ wsumNext, u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask)
+	const u32* __restrict__ rankNext, u32* __restrict__ wsumNext, u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask, u32* __restrict__ leftList, u32 leftCap)
 {
 	const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
 	const u32 numActive = counters[CTR_NUM_ACTIVE];
@@ -331,7 +345,18 @@ __global__ void __launch_bounds__(256) k_cl_assign_cached(u32* counters, u32 nb,
 		u32 numLeft = (u32)__syncthreads_count(live && phase > q);
 		if (threadIdx.x == 0 && numLeft) atomicAdd(&remainSub[(q + 1u) * CL_REMAIN_SUBS + (blockIdx.x & (CL_REMAIN_SUBS - 1u))], numLeft);
 	}
-	if (!live) return;
+	const bool toList = live && phase == numParts && numCached == numParts && !dumpAll && leftList; // left by ALL curve phases: the component phase takes it
+	if (toList)
+	{
+		const u64 m = __ballot(1);
+		const u32 lane = threadIdx.x & 63u, leader = (u32)__ffsll((long long)m) - 1u;
+		u32 base = 0;
+		if (lane == leader) base = atomicAdd(&counters[CTR_CL_LEFT], (u32)__popcll(m));
+		base = __shfl(base, leader) + (u32)__popcll(m & ((1ull << lane) - 1ull));
+		if (base < leftCap) leftList[base] = j;
+		taskKey[j] = CL_UNASSIGNED;
+	}
+	if (!live || toList) return;
 	if (goesOn)
 	{
 		taskKey[j] = CL_UNASSIGNED;
@@ -372,6 +397,80 @@ __global__ void __launch_bounds__(256) k_cl_joint_assign_cached(u32 numJoints, c
 	jointPos[i] = atomicAdd(&jointCount[t], 1u);
 	atomicOr(&phaseMask[e.z], 1u); atomicOr(&phaseMask[e.w], 1u);
 }
+
+// ---- the component phase ---------------------------------------------------------------------------------------------------------
+// What the curve phases leave over (a few per cent of the manifolds: those cut by every curve's chunk borders, in small clumps where
+// the borders cross) is not cut again: its connected components (bodies joined by left-over manifolds) are found and whole components
+// are dealt to the tasks of ONE more phase, so nothing is left for a further phase and the rest task stays empty (each phase costs a
+// hand-over and its slowest task's colours in EVERY iteration).  Union-find on the global label array (label[b] = a body of b's
+// component with a smaller or equal id; k_cl_clear set label[b] = b), a fixed number of rounds — a component that has not
+// converged by then only sends the manifolds whose ends still disagree to the rest task.  Components are
+// dealt to tasks by a hash of their label (the clumps are tens of manifolds against tasks of hundreds: the load evens out), a
+// component too large for a task is sent to the rest task.
+#define CL_COMP_ROUNDS 4u
+#define CL_COMP_MAX_WEIGHT (64u * 1400u) // a component heavier than this cannot be a task's (k_cl_color's tables): rest task
+#define CL_COMP_BLOCKS 64u               // workgroups of the component kernels (they stride over the list: its length is only known on the device)
+#define CL_LD(P_) __hip_atomic_load((P_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+MI_DEV u32 clFind(u32* label, u32 x) { u32 r = CL_LD(&label[x]); for (u32 h = 0; h < 16u; ++h) { u32 up = CL_LD(&label[r]); if (up == r) break; r = up; } return r; }
+// One round: every left-over manifold hooks the larger of its ends' roots under the smaller one, then shortens its ends' paths.  Rounds
+// are separate launches; inside a round hooks and shortcuts of different manifolds interleave freely: a label always names a body of
+// the same component with a smaller or equal id, so whatever the interleaving the labels only ever merge what belongs together, and
+// a link lost to a concurrent hook is found again by the next round (the manifold that made it is looked at in every round).
+__global__ void __launch_bounds__(256) k_cl_comp_round(const u32* __restrict__ counters, u32 nb, u32 leftCap, const u32* __restrict__ leftList, const uint4* __restrict__ actIds, u32* label)
+{
+	const u32 n = min(counters[CTR_CL_LEFT], leftCap);
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		uint4 ids = actIds[leftList[i]];
+		if (ids.x >= nb || ids.y >= nb) continue;
+		u32 ra = clFind(label, ids.x), rb = clFind(label, ids.y);
+		if (ra != rb) atomicMin(&label[max(ra, rb)], min(ra, rb));
+		atomicMin(&label[ids.x], clFind(label, ids.x));
+		atomicMin(&label[ids.y], clFind(label, ids.y));
+	}
+}
+// Weight of every component (at its label) and of the lot (counters[CTR_CL_LEFT + 2], zeroed by k_cl_clear).
+__global__ void __launch_bounds__(256) k_cl_comp_weights(u32* __restrict__ counters, u32 nb, u32 leftCap, const u32* __restrict__ leftList, const uint4* __restrict__ actIds, u32* label, u32* __restrict__ compWeight)
+{
+	const u32 n = min(counters[CTR_CL_LEFT], leftCap);
+	u32 mine = 0;
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		uint4 ids = actIds[leftList[i]];
+		u32 b = ids.x < nb ? ids.x : ids.y;
+		u32 w = clWeight(ids.z);
+		atomicAdd(&compWeight[clFind(label, b)], w);
+		mine += w;
+	}
+	for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+	if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(&counters[CTR_CL_LEFT + 2], mine);
+}
+// Deal the manifolds: both ends in one component of fitting size -> that component's task (hash of its label); otherwise the rest task.
+__global__ void __launch_bounds__(256) k_cl_comp_assign(u32* __restrict__ counters, u32 nb, u32 phase, u32 taskWeight, u32 leftCap, const u32* __restrict__ leftList, const uint4* __restrict__ actIds, u32* label,
+	const u32* __restrict__ compWeight, u32* __restrict__ taskKey, u32* __restrict__ taskPos, u32* __restrict__ taskCount, u32* __restrict__ phaseMask)
+{
+	const u32 n = min(counters[CTR_CL_LEFT], leftCap), total = counters[CTR_CL_LEFT + 2];
+	const u32 numTasks = min(max(1u, (total + taskWeight - 1u) / taskWeight), CL_MAX_TASKS);
+	if (blockIdx.x == 0 && threadIdx.x == 0) counters[CTR_CL_LEFT + 1] = numTasks;
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		const u32 j = leftList[i];
+		uint4 ids = actIds[j];
+		const bool da = ids.x < nb, db = ids.y < nb;
+		u32 la = da ? clFind(label, ids.x) : 0u, lb = db ? clFind(label, ids.y) : 0u;
+		if (!da) la = lb;
+		if (!db) lb = la;
+		u32 key = CL_MAX_PARTS * CL_MAX_TASKS;
+		if (la == lb && compWeight[la] <= CL_COMP_MAX_WEIGHT) key = phase * CL_MAX_TASKS + clHash(la * 2654435761u) % numTasks;
+		else if (la != lb) atomicAdd(&counters[CTR_CL_LEFT + 3], 1u); else atomicMax(&counters[CTR_CL_LEFT + 4], compWeight[la]); // (statistics: not converged / too large)
+		taskKey[j] = key;
+		taskPos[j] = atomicAdd(&taskCount[key * CL_SUBCOUNTERS + ((j >> 8) & (CL_SUBCOUNTERS - 1u))], 1u); // (the sub-counter k_cl_scatter derives from j's position in ITS launch)
+		const u32 ph = key / CL_MAX_TASKS;
+		if (da) atomicOr(&phaseMask[ids.x], 1u << ph);
+		if (db) atomicOr(&phaseMask[ids.y], 1u << ph);
+	}
+}
+#undef CL_LD
 
 // One workgroup: exclusive scan of the per-task counts -> first slot of every task; tasks per phase; end of schedule.
 __global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters, u32 numParts, const u32* __restrict__ taskCount, u32* __restrict__ taskStart, const u32* __restrict__ jointCount, u32* __restrict__ jointStart)
@@ -442,7 +541,7 @@ struct ClTask
 static_assert(sizeof(ClTask) == 320, "task header");
 
 __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u32 nb, const u32* __restrict__ taskStart, u32* __restrict__ pre, const uint4* __restrict__ actIds,
-	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ bodyUsers, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ mExtra, u32* __restrict__ mRank, u32* __restrict__ sharedSlot,
+	const u32* __restrict__ phaseMask, ClTask* __restrict__ tasks, u32* __restrict__ bodyList, u32* __restrict__ mOrder, u32* __restrict__ mKeySorted, u32* __restrict__ mLocal, u32* __restrict__ cEntry, u32* __restrict__ sharedSlot,
 	const u32* __restrict__ jointStart, const u32* __restrict__ jointList, const uint4* __restrict__ jointTable, uint2* __restrict__ taskJoints, u32* __restrict__ jointClassStart, u64* __restrict__ trace)
 {
 	extern __shared__ u32 clds[];
@@ -457,6 +556,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 	u32* mSlot = mCnt + CL_TASK_MAX_MANIFOLDS;          // [..] narrowphase slot | contacts << 28 (the colouring rounds' priorities hash it)
 	u32* hist = mSlot + CL_TASK_MAX_MANIFOLDS;          // [264] per key, then cursors
 	u32* jHist = hist + 264;                            // [CL_MAX_JOINT_CLASSES + 1] joints per (type, colour) class, then cursors
+	u32* cHist = jHist + CL_MAX_JOINT_CLASSES + 1;      // [CL_SERIAL_COLOR + 2] contacts per colour (64 = the serial tail), then first positions, then cursors
 	__shared__ u32 sNumShared, sNumPrivate, sMaxColor, sScan[16], sSharedBase;
 	const u32 tid = threadIdx.x;
 	// developer timeline (mi_debug_flow_trace): row 14 of the task's 16 rows = core-clock stamps of the stages below, [15] = colouring rounds
@@ -481,7 +581,7 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 		if (n > CL_TASK_MAX_MANIFOLDS || nj > CL_TASK_MAX_JOINTS) { if (tid == 0) { atomicOr(&counters[CTR_CL_STATUS], 2u); T->first = first; T->count = 0; T->numBodies = 0; T->numShared = 0; T->numColors = 0; T->serialStart = 0; T->numRows = 0; } continue; }
 		u32 phase = key / CL_MAX_TASKS;
 		for (u32 h = tid; h < CL_HASH_SIZE; h += CL_LANES) hKey[h] = 0;
-		for (u32 h = tid; h < 264u + CL_MAX_JOINT_CLASSES + 1u; h += CL_LANES) hist[h] = 0;
+		for (u32 h = tid; h < 264u + CL_MAX_JOINT_CLASSES + 1u + CL_SERIAL_COLOR + 2u; h += CL_LANES) hist[h] = 0;
 		if (tid == 0) { sNumShared = 0; sNumPrivate = 0; sMaxColor = 0; }
 		__syncthreads();
 		CL_STAMP(0)
@@ -701,8 +801,16 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 		for (u32 r = 0; r < 2u; ++r) { u32 i = tid + r * CL_LANES; if (i < n) mKey[i] = rKey[r]; }
 		__syncthreads();
 		CL_STAMP(4)
-		// 4. order by key: histogram, scan by one wave, cursors
-		for (u32 i = tid; i < n; i += CL_LANES) atomicAdd(&hist[mKey[i]], 1u);
+		// 4. manifold order by key = (first colour, contact count): histogram, scan by one wave, cursors.  This is the order the rows are
+		// initialised in and the schedule export reports (manifold after manifold; manifolds that share a body have disjoint colour runs).
+		for (u32 i = tid; i < n; i += CL_LANES)
+		{
+			const u32 k = mKey[i], c = k >> 2, cnt = 4u - (k & 3u);
+			atomicAdd(&hist[k], 1u);
+			// ... and the CONTACT histogram per colour (contact q of a manifold runs in colour c + q; the serial tail is class 64)
+			if (c < CL_SERIAL_COLOR) { for (u32 q = 0; q < cnt; ++q) atomicAdd(&cHist[c + q], 1u); }
+			else atomicAdd(&cHist[CL_SERIAL_COLOR], cnt);
+		}
 		__syncthreads();
 		if (tid < 64u) // 260 keys, 5 per lane (65 colours x 4 counts): serial scan over 64 lanes
 		{
@@ -713,20 +821,23 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 			for (int o = 1; o < 64; o <<= 1) { u32 up = __shfl_up(incl, o); if ((int)tid >= o) incl += up; }
 			u32 run = incl - s;
 			for (u32 k = 0; k < 5u; ++k) { if (base + k < 260u) hist[base + k] = run; run += v[k]; }
-			// number of colours in use = highest non-empty colour below the serial class + 1
-			u32 top = 0;
-			for (u32 k = 0; k < 5u; ++k) if (v[k] && (base + k) / 4u < CL_SERIAL_COLOR) top = (base + k) / 4u + 1u;
+			// contacts per colour -> first contact position of every colour (lane = colour); number of colours in use
+			const u32 cc = cHist[tid];
+			u32 ci = cc;
+			for (int o = 1; o < 64; o <<= 1) { u32 up = __shfl_up(ci, o); if ((int)tid >= o) ci += up; }
+			const u32 coloured = (u32)__shfl(ci, 63), serial = cHist[CL_SERIAL_COLOR];
+			u32 top = cc ? tid + 1u : 0u;
 			for (int o = 32; o > 0; o >>= 1) top = max(top, (u32)__shfl_xor(top, o));
-			if (tid == 0) sMaxColor = top;
+			cHist[tid] = ci - cc;
+			if (tid == 0) { cHist[CL_SERIAL_COLOR] = coloured; cHist[CL_SERIAL_COLOR + 1u] = coloured + serial; sMaxColor = top; }
 		}
 		__syncthreads();
-		const u32 numColors = sMaxColor;
-		if (tid <= CL_SERIAL_COLOR) T->colorStart[tid] = hist[tid * 4u];
+		const u32 numColors = sMaxColor, numContacts = cHist[CL_SERIAL_COLOR + 1u], serialStartC = cHist[CL_SERIAL_COLOR];
+		if (tid <= CL_SERIAL_COLOR + 1u) T->colorStart[tid] = cHist[tid];
 		if (tid == 0)
 		{
-			T->first = first; T->count = n; T->numBodies = numBodies; T->numShared = numShared; T->numColors = numColors; T->serialStart = hist[CL_SERIAL_COLOR * 4u];
-			T->colorStart[CL_SERIAL_COLOR + 1u] = n;
-			atomicMax(&counters[CTR_NUM_COLORS], numColors + (hist[CL_SERIAL_COLOR * 4u] < n ? 1u : 0u));
+			T->first = first; T->count = n; T->numBodies = numBodies; T->numShared = numShared; T->numColors = numColors; T->serialStart = serialStartC; T->numRows = numContacts;
+			atomicMax(&counters[CTR_NUM_COLORS], numColors + (serialStartC < numContacts ? 1u : 0u));
 			T->sharedBase = sharedBase;
 			atomicAdd(&counters[CTR_CL_PHASE_COUNT + phase], n);
 		}
@@ -738,66 +849,32 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 		{
 			u32 k = mKey[i], p;
 			if ((k >> 2) < CL_SERIAL_COLOR) p = atomicAdd(&hist[k], 1u);
-			else { p = hist[k]; for (u32 j = 0; j < i; ++j) p += (mKey[j] == k) ? 1u : 0u; } // (rare: a body with more than 64 users in one task)
-			mPos[i] = p; mCnt[p] = (4u - (k & 3u));
+			else { p = hist[k]; for (u32 j = 0; j < i; ++j) p += (mKey[j] == k) ? 1u : 0u; } // (rare: a body with more than 64 contacts in one task)
+			mPos[i] = p;
 		}
 		__syncthreads();
 		CL_STAMP(5)
-		// 5. extra-row offsets: exclusive scan of (count - 1) over the final positions (2 per lane)
-		{
-			u32 p0 = 2u * tid, e0 = (p0 < n) ? mCnt[p0] - 1u : 0u, e1 = (p0 + 1u < n) ? mCnt[p0 + 1u] - 1u : 0u;
-			u32 s = e0 + e1, incl = s;
-			for (int o = 1; o < 64; o <<= 1) { u32 up = __shfl_up(incl, o); if ((int)(tid & 63u) >= o) incl += up; }
-			if ((tid & 63u) == 63u) sScan[tid >> 6] = incl;
-			__syncthreads();
-			u32 waveBase = 0;
-			for (u32 wv = 0; wv < (tid >> 6); ++wv) waveBase += sScan[wv];
-			u32 excl = waveBase + incl - s;
-			__syncthreads();
-			if (p0 < n) mCnt[p0] = excl;
-			if (p0 + 1u < n) mCnt[p0 + 1u] = excl + e0;
-			if (tid == CL_LANES - 1u) T->numRows = n + waveBase + incl;
-		}
-		__syncthreads();
-		CL_STAMP(6)
-		// 6. rank of every manifold among the users of each of its bodies, in position order (the hand-over turn numbers).
-		// Coloured manifolds: a colour occurs once per body, so the rank is the number of lower colours in the body's mask.  The serial
-		// tail (no colour left below 64: bodies with more than 64 users in this task) is walked by one lane in position order.
-		u32* inv = hKey;   // serial manifolds by position (the hash is no longer needed)
-		u32* rankL = hVal; // per manifold: rA | dA << 8 | rB << 16 | dB << 24 (d filled in below)
-		const u32 serialStart = hist[CL_SERIAL_COLOR * 4u - 1u]; // cursors have run: cursor of the last coloured class = first serial position
-		for (u32 l = tid; l < numBodies; l += CL_LANES) claim[l] = 0; // serial users per body
-		for (u32 i = tid; i < n; i += CL_LANES) if ((mKey[i] >> 2) >= CL_SERIAL_COLOR) inv[mPos[i] - serialStart] = i;
-		__syncthreads();
-		if (tid == 0)
-			for (u32 p = serialStart; p < n; ++p)
-			{
-				u32 i = inv[p - serialStart], ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16, r = 0;
-				if (la != CL_LOCAL_STATIC) { r |= ((u32)__popcll(mask[la]) + claim[la]) & 0xFFu; claim[la]++; }
-				if (lb != CL_LOCAL_STATIC) { r |= (((u32)__popcll(mask[lb]) + claim[lb]) & 0xFFu) << 16; claim[lb]++; }
-				rankL[i] = r;
-			}
-		__syncthreads();
-		bool tooBusy = false;
-		for (u32 l = tid; l < numBodies; l += CL_LANES)
-		{
-			u32 users = (u32)__popcll(mask[l]) + claim[l];
-			if (users > 250u) tooBusy = true; // the turn arithmetic keeps ranks and user counts in 8 bits
-			bodyUsers[(size_t)key * CL_BODY_STRIDE + l] = users;
-		}
-		if (tooBusy) atomicOr(&counters[CTR_CL_STATUS], 2u);
+		// 5. the contact schedule: contact q of a manifold of first colour c gets a position inside colour c + q (cursor: free order
+		// inside a colour); the serial tail's contacts follow in manifold position order, a manifold's contacts in order.
+		// Entry = manifold position inside the task | q << 12.
 		for (u32 i = tid; i < n; i += CL_LANES)
 		{
-			u32 p = mPos[i], ab = mAB[i], la = ab & 0xFFFFu, lb = ab >> 16, c = mKey[i] >> 2;
-			u32 r = (c >= CL_SERIAL_COLOR) ? rankL[i] : 0u;
-			u64 lower = (c >= CL_SERIAL_COLOR) ? 0ull : ((1ull << c) - 1ull);
-			if (la != CL_LOCAL_STATIC) { if (c < CL_SERIAL_COLOR) r |= (u32)__popcll(mask[la] & lower); r |= ((((u32)__popcll(mask[la]) + claim[la])) & 0xFFu) << 8; }
-			if (lb != CL_LOCAL_STATIC) { if (c < CL_SERIAL_COLOR) r |= (u32)__popcll(mask[lb] & lower) << 16; r |= ((((u32)__popcll(mask[lb]) + claim[lb])) & 0xFFu) << 24; }
+			const u32 k = mKey[i], c = k >> 2, cnt = 4u - (k & 3u), mp = mPos[i];
+			if (c < CL_SERIAL_COLOR) { for (u32 q = 0; q < cnt; ++q) cEntry[(size_t)4u * first + atomicAdd(&cHist[c + q], 1u)] = mp | (q << 12); }
+			else
+			{
+				u32 p = serialStartC;
+				for (u32 j = 0; j < n; ++j) if ((mKey[j] >> 2) >= CL_SERIAL_COLOR && mPos[j] < mp) p += 4u - (mKey[j] & 3u);
+				for (u32 q = 0; q < cnt; ++q) cEntry[(size_t)4u * first + p + q] = mp | (q << 12);
+			}
+		}
+		CL_STAMP(6)
+		for (u32 i = tid; i < n; i += CL_LANES)
+		{
+			u32 p = mPos[i];
 			mOrder[first + p] = pre[first + i];
 			mKeySorted[first + p] = mKey[i];
-			mLocal[first + p] = ab;
-			mExtra[first + p] = mCnt[p];
-			mRank[first + p] = r;
+			mLocal[first + p] = mAB[i];
 		}
 		__syncthreads();
 		CL_STAMP(7)
@@ -809,41 +886,37 @@ __global__ void __launch_bounds__(1024) k_cl_color(u32* __restrict__ counters, u
 // ---------------------------------------------------------------------------------------------------------------
 // The sweep.
 // ---------------------------------------------------------------------------------------------------------------
+// FOUR lanes (a quad) work on one contact row: lane q owns one of the row's four body vectors x (q = 0: vA, 1: wA, 2: vB, 3: wB — one
+// float4 of the body's LDS record) and its pieces of the row: dT / dN = what x is dotted with in the tangent / normal row velocity
+// (body A's negated), aT / aN = what an impulse adds to x (inverse mass and sign folded in).  A row velocity is the sum of the
+// four lanes' 3-term dots — two DPP adds inside the quad, every lane gets the bit-identical total (p0 + p1) + (p2 + p3) — the
+// impulse update is done by all four lanes redundantly, each then updates its vector: solver_rows.h's solveRow, lane for lane.
+// Measured against one lane per manifold (tests/micro/colorstep.hip): a colour step is ONE LDS access each way and ~27 vector
+// instructions per lane instead of four and ~66 — 344 cycles against 707, 450 against 1 880 when all eight waves have work — and a
+// manifold of k contacts is k such steps (its contacts run in consecutive colours) instead of one step of 700 + 465 (k - 1) cycles.
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+struct QuadRow { V3 dT, aT, dN, aN; float mT, mN, bias, friction, lamN, lamT; }; // 18 floats per lane
+#define CLQ_ZERO_FLOAT4S (2u * CLQ_QUADS + 4u)
+#define CLQ_ROW_FLOAT4S 14u // a contact row outside the registers (LDS, or the global scratch beyond LDS): per lane q three float4 {dT, aT.x} {aT.yz, dN.xy} {dN.z, aN} at 3 q, then {mT, mN, bias, friction}, {lamN, lamT, addresses of lanes 0 | 1 << 16, 2 | 3 << 16}
 
 struct ClLocal // a task of this workgroup, in LDS
 {
-	u32 first, count, numBodies, numShared, numColors, serialStart, phase, key, sharedBase, numJoints;
-	u32 bodyOff;   // float4 index of the task's bodies (2 float4 each)
-	u32 infoOff;   // u32 index (in float4 units * 4) of per-body {global id, turn info}
-	u32 metaOff;   // float4 index of the per-manifold meta (not for the register task): {la|lb<<16, key|extra<<10, -, -}, {n.xyz, friction}
-	u32 rowOff;    // float4 index of the row planes
-	u32 rowCap;    // rows of this task that live in LDS
-	u32 inRegs;    // the first contact row of every manifold sits in its lane's registers
-	u32 colorStart[66];
+	u32 first, count, numBodies, numShared, numColors, serialStart, numContacts, phase, key, sharedBase, numJoints;
+	u32 bodyOff;     // float4 index of the task's bodies (2 float4 each)
+	u32 infoOff;     // u32 index of per-body {global id, turn info, hand-over record}
+	u32 regContacts; // contacts [0, regContacts) live in the lanes' register sets (the workgroup's first task only)
+	u32 rowOff;      // float4 index of the rows kept in LDS: contacts [regContacts, regContacts + rowCap)
+	u32 rowCap;      // ... the rest, contacts [regContacts + rowCap, numContacts), in the global scratch from scratchBase on
+	u32 scratchBase;
+	u32 colorStart[68];
 };
-
-// Row r of a task's LDS row region: 8 float4 planes, plane-major (consecutive rows -> consecutive addresses); plane 7 = {mT, bias, lambdaN, lambdaT}.
-MI_DEV void clLoadRowLds(ContactRow& r, const float4* lds, u32 rowOff, u32 rowCap, u32 row)
-{
-	const float4* P = lds + rowOff + row;
-	r.p0 = P[0]; r.p1 = P[rowCap]; r.p2 = P[2 * rowCap]; r.p3 = P[3 * rowCap]; r.p4 = P[4 * rowCap]; r.p5 = P[5 * rowCap]; r.p6 = P[6 * rowCap];
-	float4 q = P[7 * rowCap]; r.p7 = make_float2(q.x, q.y); r.lam = make_float2(q.z, q.w);
-}
-MI_DEV void clStoreRowLds(float4* lds, u32 rowOff, u32 rowCap, u32 row, const ContactRow& r)
-{
-	float4* P = lds + rowOff + row;
-	P[0] = r.p0; P[rowCap] = r.p1; P[2 * rowCap] = r.p2; P[3 * rowCap] = r.p3; P[4 * rowCap] = r.p4; P[5 * rowCap] = r.p5; P[6 * rowCap] = r.p6;
-	P[7 * rowCap] = make_float4(r.p7.x, r.p7.y, r.lam.x, r.lam.y);
-}
-MI_DEV void clStoreLambdaLds(float4* lds, u32 rowOff, u32 rowCap, u32 row, float2 lam) { ((float2*)(lds + rowOff + 7 * rowCap + row))[1] = lam; }
-MI_DEV float2 clLoadLambdaLds(const float4* lds, u32 rowOff, u32 rowCap, u32 row) { return ((const float2*)(lds + rowOff + 7 * rowCap + row))[1]; }
 
 struct ClArgs
 {
-	u32* counters; const ClTask* tasks; const u32* bodyList; const u32* bodyUsers; const u32* phaseMask; const u32* sharedSlot;
-	const u32* mKeySorted; const u32* mLocal; const u32* mExtra; const u32* mRank;
-	const float4* rowPlanes; const float4* rowShared; float2* rowLambda;
+	u32* counters; const ClTask* tasks; const u32* bodyList; const u32* phaseMask; const u32* sharedSlot;
+	const u32* mKeySorted; const u32* mLocal; const u32* cEntry;
+	const float4* rowPlanes; const float4* rowShared; float2* rowLambda; float4* rowScratch; u32 scratchContacts;
 	u32 predictDiv, pollSleep; // pacing of the hand-over polls (MI_CLUSTER_PREDICT_DIV / MI_CLUSTER_POLL_SLEEP)
 	float4* vel; u64* flow; u64* trace; // trace: developer timeline (mi_debug_flow_trace), normally null
 	size_t rowCap; u32 nb, flowBytes, epoch, itBegin, itEnd, ldsFloat4s;
@@ -853,106 +926,60 @@ struct ClArgs
 	const u32* jointClassStart; const uint2* taskJoints; const uint4* jointTable; float* jointUpd[MI_JOINT_TYPES]; const float4* invIw; u32 numJointClasses;
 };
 
-// One manifold: both bodies from LDS, its rows (registers / LDS / global memory), both bodies back.
-template <bool REG> MI_DEV void clSolveManifold(float4* lds, const ClLocal& L, const ClArgs& A, u32 pos, u32 ab, u32 keyExtra, float4 sh, ContactRow& r0)
+MI_DEV float clQuadSum(float p)
 {
-	u32 la = ab & 0xFFFFu, lb = ab >> 16;
-	u32 count = 4u - (keyExtra & 3u), extra = keyExtra >> 10;
-	float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, b0 = a0, b1 = a0;
-	if (la != CL_LOCAL_STATIC) { a0 = lds[L.bodyOff + 2 * la]; a1 = lds[L.bodyOff + 2 * la + 1]; }
-	if (lb != CL_LOCAL_STATIC) { b0 = lds[L.bodyOff + 2 * lb]; b1 = lds[L.bodyOff + 2 * lb + 1]; }
-	V3 vA = v3f4(a0), wA = v3f4(a1), vB = v3f4(b0), wB = v3f4(b1);
-	float invMassA = a0.w, invMassB = b0.w;
-	V3 n = v3(sh.x, sh.y, sh.z);
-	float friction = sh.w;
-	u32 slot = L.first + pos;
-	u32 rowBase = REG ? extra : pos + extra; // LDS row of contact 1 (register task) or contact 0
-	for (u32 k = 0; k < count; ++k)
-	{
-		if (REG && k == 0) { solveRow(r0, n, friction, invMassA, invMassB, vA, wA, vB, wB); continue; }
-		u32 row = rowBase + (REG ? k - 1u : k);
-		ContactRow cur;
-		if (row < L.rowCap)
-		{
-			clLoadRowLds(cur, lds, L.rowOff, L.rowCap, row);
-			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
-			clStoreLambdaLds(lds, L.rowOff, L.rowCap, row, cur.lam);
-		}
-		else // beyond the LDS budget: streamed from global memory every iteration
-		{
-			loadRow(cur, k, slot, A.rowCap, A.rowPlanes, A.rowLambda);
-			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
-			A.rowLambda[(size_t)k * A.rowCap + slot] = cur.lam;
-		}
-	}
-	if (la != CL_LOCAL_STATIC) { lds[L.bodyOff + 2 * la] = make_float4(vA.x, vA.y, vA.z, invMassA); lds[L.bodyOff + 2 * la + 1] = make_float4(wA.x, wA.y, wA.z, 0.f); }
-	if (lb != CL_LOCAL_STATIC) { lds[L.bodyOff + 2 * lb] = make_float4(vB.x, vB.y, vB.z, invMassB); lds[L.bodyOff + 2 * lb + 1] = make_float4(wB.x, wB.y, wB.z, 0.f); }
+	float q = p + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, false)); // quad_perm [1, 0, 3, 2]: lin + ang of one body
+	return q + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, q), 0x4E, 0xF, 0xF, false));   // quad_perm [2, 3, 0, 1]: body A's + body B's
 }
-
-// The same for a manifold of the register task, with everything address-like resolved beforehand: rd / wr are the float4 indices of
-// the two bodies (a static body reads the all-zero record and writes into a sink, so there is no branch around the LDS traffic),
-// rowOff / rowCap / slot come in registers instead of being re-read from the task record in LDS behind every barrier
-// (each such read is a dependent LDS round trip of ~100 cycles on the sweep's critical path).
-MI_DEV void clSolveReg(float4* lds, const ClArgs& A, u32 rdA, u32 wrA, u32 rdB, u32 wrB, u32 keyExtra, float4 sh, ContactRow& r0, u32 rowOff, u32 rowCap, u32 slot)
+// One contact row (friction, then normal: constraints.cpp:3404-3442) on this lane's body vector x.
+MI_DEV void clSolveQuad(QuadRow& r, V3& x)
 {
-	float4 a0 = lds[rdA], a1 = lds[rdA + 1], b0 = lds[rdB], b1 = lds[rdB + 1];
-	V3 vA = v3f4(a0), wA = v3f4(a1), vB = v3f4(b0), wB = v3f4(b1);
-	float invMassA = a0.w, invMassB = b0.w;
-	V3 n = v3(sh.x, sh.y, sh.z);
-	float friction = sh.w;
-	solveRow(r0, n, friction, invMassA, invMassB, vA, wA, vB, wB);
-	u32 count = 4u - (keyExtra & 3u), extra = keyExtra >> 10;
-	for (u32 k = 1; k < count; ++k)
-	{
-		u32 row = extra + k - 1u;
-		ContactRow cur;
-		if (row < rowCap)
-		{
-			clLoadRowLds(cur, lds, rowOff, rowCap, row);
-			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
-			clStoreLambdaLds(lds, rowOff, rowCap, row, cur.lam);
-		}
-		else // beyond the LDS budget: streamed from global memory every iteration
-		{
-			loadRow(cur, k, slot, A.rowCap, A.rowPlanes, A.rowLambda);
-			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
-			A.rowLambda[(size_t)k * A.rowCap + slot] = cur.lam;
-		}
-	}
-	lds[wrA] = make_float4(vA.x, vA.y, vA.z, invMassA); lds[wrA + 1] = make_float4(wA.x, wA.y, wA.z, 0.f);
-	lds[wrB] = make_float4(vB.x, vB.y, vB.z, invMassB); lds[wrB + 1] = make_float4(wB.x, wB.y, wB.z, 0.f);
+	float vt = clQuadSum(rowDot3(x, r.dT));
+	float maxFriction = r.friction * r.lamN;
+	float newT = rowClampSym(__builtin_fmaf(-r.mT, vt, r.lamT), maxFriction);
+	float d = newT - r.lamT; r.lamT = newT;
+	x = rowFma(d, r.aT, x);
+	float vn = clQuadSum(rowDot3(x, r.dN));
+	float newN = fmaxf(__builtin_fmaf(-r.mN, vn - r.bias, r.lamN), 0.f);
+	d = newN - r.lamN; r.lamN = newN;
+	x = rowFma(d, r.aN, x);
 }
-
-// A manifold of the workgroup's SECOND task: its rows all live in LDS (or, beyond the budget, in global memory), but what a lane needs to
-// find them — body addresses, key, shared normal — sits in its registers like the first task's, so a colour step is ONE LDS round trip
-// (bodies and first row together) instead of the generic path's chain task record -> meta -> bodies / rows.
-MI_DEV void clSolveLds(float4* lds, const ClArgs& A, u32 rdA, u32 wrA, u32 rdB, u32 wrB, u32 keyExtra, float4 sh, u32 rowBase, u32 rowOff, u32 rowCap, u32 slot)
+// Lane q's view of contact position p of task L, from the global row planes: its pieces of the row and the LDS address of its body
+// vector (a static body: the all-zero record; its apply vectors are zero, so what is written back is the zero that was read).
+MI_DEV void clBuildQuadRow(QuadRow& r, u32& addr, const ClLocal& L, const ClArgs& A, const float4* lds, u32 p, u32 q, u32 zeroRec, u32& slotOut, u32& kOut)
 {
-	float4 a0 = lds[rdA], a1 = lds[rdA + 1], b0 = lds[rdB], b1 = lds[rdB + 1];
-	V3 vA = v3f4(a0), wA = v3f4(a1), vB = v3f4(b0), wB = v3f4(b1);
-	float invMassA = a0.w, invMassB = b0.w;
-	V3 n = v3(sh.x, sh.y, sh.z);
-	float friction = sh.w;
-	u32 count = 4u - (keyExtra & 3u);
-	for (u32 k = 0; k < count; ++k)
-	{
-		u32 row = rowBase + k;
-		ContactRow cur;
-		if (row < rowCap)
-		{
-			clLoadRowLds(cur, lds, rowOff, rowCap, row);
-			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
-			clStoreLambdaLds(lds, rowOff, rowCap, row, cur.lam);
-		}
-		else // beyond the LDS budget: streamed from global memory every iteration
-		{
-			loadRow(cur, k, slot, A.rowCap, A.rowPlanes, A.rowLambda);
-			solveRow(cur, n, friction, invMassA, invMassB, vA, wA, vB, wB);
-			A.rowLambda[(size_t)k * A.rowCap + slot] = cur.lam;
-		}
-	}
-	lds[wrA] = make_float4(vA.x, vA.y, vA.z, invMassA); lds[wrA + 1] = make_float4(wA.x, wA.y, wA.z, 0.f);
-	lds[wrB] = make_float4(vB.x, vB.y, vB.z, invMassB); lds[wrB + 1] = make_float4(wB.x, wB.y, wB.z, 0.f);
+	const u32 e = A.cEntry[(size_t)4u * L.first + p], mp = e & 0xFFFu, k = e >> 12, slot = L.first + mp;
+	const u32 ab = A.mLocal[slot], local = q < 2u ? (ab & 0xFFFFu) : (ab >> 16);
+	const float4 sh = A.rowShared[slot];
+	ContactRow row; loadRow(row, k, slot, A.rowCap, A.rowPlanes, A.rowLambda);
+	const bool isStatic = local == CL_LOCAL_STATIC;
+	addr = (isStatic ? zeroRec : L.bodyOff + 2u * local) + (q & 1u);
+	const float invMass = isStatic ? 0.f : lds[L.bodyOff + 2u * local].w; // (.w of a body's first float4 = its inverse mass, constant over the launch)
+	const V3 t = v3(row.p0.x, row.p0.y, row.p0.z), n = v3(sh.x, sh.y, sh.z);
+	if (q == 0u) { r.dT = -t; r.aT = -(invMass * t); r.dN = -n; r.aN = -(invMass * n); }
+	else if (q == 1u) { r.dT = -v3(row.p0.w, row.p1.x, row.p1.y); r.aT = -v3(row.p3.w, row.p4.x, row.p4.y); r.dN = -v3(row.p2.y, row.p2.z, row.p2.w); r.aN = -v3(row.p5.y, row.p5.z, row.p5.w); }
+	else if (q == 2u) { r.dT = t; r.aT = invMass * t; r.dN = n; r.aN = invMass * n; }
+	else { r.dT = v3(row.p1.z, row.p1.w, row.p2.x); r.aT = v3(row.p4.z, row.p4.w, row.p5.x); r.dN = v3(row.p3.x, row.p3.y, row.p3.z); r.aN = v3(row.p6.x, row.p6.y, row.p6.z); }
+	r.mT = row.p7.x; r.mN = row.p6.w; r.bias = row.p7.y; r.friction = sh.w; r.lamN = row.lam.x; r.lamT = row.lam.y;
+	slotOut = slot; kOut = k;
+}
+// Row storage outside the registers (P = the contact's CLQ_ROW_FLOAT4S float4): every lane stores its vectors, lane 0 the scalars and lane
+// 0 / 2 the packed addresses of their pair of lanes (the addresses of a quad: two bodies x {linear, angular} = base and base + 1).
+template <typename PTR> MI_DEV void clStoreQuadRow(PTR P, u32 q, const QuadRow& r, u32 addr)
+{
+	P[3u * q] = make_float4(r.dT.x, r.dT.y, r.dT.z, r.aT.x); P[3u * q + 1u] = make_float4(r.aT.y, r.aT.z, r.dN.x, r.dN.y); P[3u * q + 2u] = make_float4(r.dN.z, r.aN.x, r.aN.y, r.aN.z);
+	if (q == 0u) P[12] = make_float4(r.mT, r.mN, r.bias, r.friction);
+	const u32 other = (u32)__builtin_amdgcn_update_dpp(0, (int)addr, 0xB1, 0xF, 0xF, false); // the partner lane's address (quad_perm [1, 0, 3, 2])
+	const u32 otherPair = (u32)__builtin_amdgcn_update_dpp(0, (int)(addr | (other << 16)), 0x4E, 0xF, 0xF, false); // lanes 2 | 3 << 16 seen from lane 0
+	if (q == 0u) P[13] = make_float4(r.lamN, r.lamT, __uint_as_float(addr | (other << 16)), __uint_as_float(otherPair));
+}
+template <typename PTR> MI_DEV void clLoadQuadRow(QuadRow& r, u32& addr, PTR P, u32 q)
+{
+	float4 a = P[3u * q], b = P[3u * q + 1u], c = P[3u * q + 2u], d = P[12], e = P[13];
+	r.dT = v3f4(a); r.aT = v3(a.w, b.x, b.y); r.dN = v3(b.z, b.w, c.x); r.aN = v3(c.y, c.z, c.w);
+	r.mT = d.x; r.mN = d.y; r.bias = d.z; r.friction = d.w; r.lamN = e.x; r.lamT = e.y;
+	const u32 pair = __float_as_uint(q < 2u ? e.z : e.w);
+	addr = (q & 1u) ? (pair >> 16) : (pair & 0xFFFFu);
 }
 
 // JOINTS: the instantiation for worlds whose joints run inside the sweep (its extra registers and code stay out of the other one).
@@ -961,9 +988,14 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 	extern __shared__ float4 lds[];
 	__shared__ ClLocal sTask[CL_MAX_LOCAL_TASKS];
 	__shared__ u32 sNumTasks, sAbort;
-	const u32 tid = threadIdx.x, G = gridDim.x;
+	const u32 tid = threadIdx.x, G = gridDim.x, quad = tid >> 2, q = tid & 3u;
+	constexpr u32 SETS = JOINTS ? CLQ_SETS_JOINTS : CLQ_SETS;
 	u32* status = A.counters + CTR_FLOW_STATUS;
 	__amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(A.flow, 0, A.flowBytes, 0x00020000);
+	// The static body: an all-zero record.  Its apply vectors are zero, so a contact lane writes back the zero it read; every quad has its own copy
+	// (CLQ_ZERO_FLOAT4S float4 at the end of LDS: a third of a pile's contacts touch the ground, and same-address writes of one wave
+	// instruction are served one after the other).  The joints read a shared copy and write into a sink.
+	const u32 zeroBase = A.ldsFloat4s - CLQ_ZERO_FLOAT4S, zeroRec = zeroBase + 2u * CLQ_QUADS, sinkRec = zeroRec + 2u;
 
 	// ---- which tasks are mine, and where they live in LDS ----
 	if (tid == 0)
@@ -987,29 +1019,30 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 				if (!T->count && !tj) continue;
 				if (nT == CL_MAX_LOCAL_TASKS) { bad = true; break; }
 				ClLocal& L = sTask[nT];
-				L.first = T->first; L.count = T->count; L.numBodies = T->numBodies; L.numShared = T->numShared; L.numColors = T->numColors; L.serialStart = T->serialStart;
+				L.first = T->first; L.count = T->count; L.numBodies = T->numBodies; L.numShared = T->numShared; L.numColors = T->numColors; L.serialStart = T->serialStart; L.numContacts = T->numRows;
 				L.phase = p; L.key = key; L.sharedBase = T->sharedBase; L.numJoints = tj;
 				if (tj > CLS_LANES || (tj && nT)) bad = true; // one lane per joint; joints run with the workgroup's first task only
 				for (u32 c = 0; c <= CL_SERIAL_COLOR + 1u; ++c) L.colorStart[c] = T->colorStart[c];
+				L.colorStart[CL_SERIAL_COLOR + 2u] = L.colorStart[CL_SERIAL_COLOR + 1u]; L.colorStart[CL_SERIAL_COLOR + 3u] = L.colorStart[CL_SERIAL_COLOR + 1u]; // (the colour loop reads two entries ahead)
 				L.bodyOff = used; used += 2u * L.numBodies;
 				L.infoOff = used * 4u; used += (3u * L.numBodies + 3u) / 4u;
-				L.inRegs = (nT == 0 && L.count <= CLS_LANES * CLS_R) ? 1u : 0u;
-				L.metaOff = used; if (!L.inRegs) used += 2u * L.count;
+				L.regContacts = (nT == 0) ? min(L.numContacts, CLQ_QUADS * SETS) : 0u;
 				L.rowOff = 0; L.rowCap = 0;
 				++nT;
 			}
 		}
-		// rows: whatever LDS is left, in task order (7 plane-rows of 16 B per row: 6 float4 + 1 float2 rounded up)
-		for (u32 k = 0; k < nT; ++k)
+		if (used + CLQ_ZERO_FLOAT4S > A.ldsFloat4s) bad = true; // the bodies alone exceed LDS: cannot run this launch
+		// rows beyond the register sets: whatever LDS is left, in task order
+		for (u32 k = 0; k < nT && !bad; ++k)
 		{
 			ClLocal& L = sTask[k];
-			u32 want = A.tasks[L.key].numRows - (L.inRegs ? L.count : 0u);
-			u32 left = (used + 4u < A.ldsFloat4s) ? A.ldsFloat4s - used - 4u : 0u; // the last four float4 are the static body's all-zero record and the sink its writes go to
-			u32 fit = left / 8u;                          // 8 float4 per row
-			u32 cap = want < fit ? want : fit;
-			L.rowOff = used; L.rowCap = cap; used += 8u * cap;
+			u32 want = L.numContacts - L.regContacts;
+			u32 left = A.ldsFloat4s - used - CLQ_ZERO_FLOAT4S; // (the end of LDS holds the static body's all-zero records and the sink)
+			u32 fit = left / CLQ_ROW_FLOAT4S;
+			u32 cap = want < fit ? want : fit;              // what does not fit goes to the global scratch (L2-resident, every step of such a task waits for it: the cluster build sizes the later phases' tasks so that this is rare)
+			L.rowOff = used; L.rowCap = cap; used += CLQ_ROW_FLOAT4S * cap; L.scratchBase = 0;
+			if (want > cap) { L.scratchBase = atomicAdd(&A.counters[CTR_CL_SCRATCH], want - cap); if (L.scratchBase + (want - cap) > A.scratchContacts) { bad = true; break; } }
 		}
-		if (used + 4u > A.ldsFloat4s) bad = true; // bodies + meta alone exceed LDS: cannot run this launch
 		if (bad) atomicOr(status, 64u);
 		sNumTasks = nT; sAbort = (bad || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1u : 0u;
 	}
@@ -1018,9 +1051,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 	const u32 numTasks = sNumTasks;
 	if (!numTasks) return;
 
-	// ---- prologue: bodies, meta, rows ----
-	static_assert(CLS_R == 2u, "two named register sets below");
-	u32 regAB0 = 0, regAB1 = 0, regKE0 = 0xFFFFFFFFu, regKE1 = 0xFFFFFFFFu; float4 regSh0 = make_float4(0.f, 0.f, 0.f, 0.f), regSh1 = regSh0; ContactRow regRow0 = {}, regRow1 = {}, noRow = {};
+	// ---- prologue: bodies, then the rows ----
 	for (u32 k = 0; k < numTasks; ++k)
 	{
 		const ClLocal& L = sTask[k];
@@ -1038,75 +1069,57 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 			info[3 * l + 2] = (l < L.numShared) ? A.sharedSlot[(size_t)prev * (A.nb + 1u) + g] : 0u;
 			lds[L.bodyOff + 2 * l] = A.vel[2 * g]; lds[L.bodyOff + 2 * l + 1] = A.vel[2 * g + 1]; // shared ones too: .w = invMass stays, the rest is replaced at every acquire
 		}
-		if (L.inRegs)
-		{
-#define CL_LOAD_REG(R_, AB_, KE_, SH_, ROW_) \
-			{ \
-				u32 i = tid + (R_) * CLS_LANES; \
-				if (i < L.count) \
-				{ \
-					u32 slot = L.first + i; \
-					u32 key = A.mKeySorted[slot], extra = A.mExtra[slot], count = 4u - (key & 3u); \
-					AB_ = A.mLocal[slot]; KE_ = key | (extra << 10); SH_ = A.rowShared[slot]; \
-					loadRow(ROW_, 0, slot, A.rowCap, A.rowPlanes, A.rowLambda); \
-					for (u32 kk = 1; kk < count; ++kk) \
-					{ \
-						u32 row = extra + kk - 1u; \
-						if (row >= L.rowCap) continue; \
-						ContactRow cur; \
-						loadRow(cur, kk, slot, A.rowCap, A.rowPlanes, A.rowLambda); \
-						clStoreRowLds(lds, L.rowOff, L.rowCap, row, cur); \
-					} \
-				} \
-			}
-			CL_LOAD_REG(0u, regAB0, regKE0, regSh0, regRow0)
-			CL_LOAD_REG(1u, regAB1, regKE1, regSh1, regRow1)
-#undef CL_LOAD_REG
-		}
-		else for (u32 i = tid; i < L.count; i += CLS_LANES)
-		{
-			u32 slot = L.first + i;
-			u32 key = A.mKeySorted[slot], extra = A.mExtra[slot], count = 4u - (key & 3u);
-			lds[L.metaOff + 2 * i] = make_float4(__uint_as_float(A.mLocal[slot]), __uint_as_float(key | (extra << 10)), 0.f, 0.f);
-			lds[L.metaOff + 2 * i + 1] = A.rowShared[slot];
-			for (u32 kk = 0; kk < count; ++kk)
-			{
-				u32 row = i + extra + kk;
-				if (row >= L.rowCap) continue;
-				ContactRow cur;
-				loadRow(cur, kk, slot, A.rowCap, A.rowPlanes, A.rowLambda);
-				clStoreRowLds(lds, L.rowOff, L.rowCap, row, cur);
-			}
-		}
 	}
-	// the register task's bodies as LDS addresses (static body: read the zero record, write into the sink)
-	const u32 zeroRec = A.ldsFloat4s - 4u, sinkRec = A.ldsFloat4s - 2u;
-	if (tid < 2u) lds[zeroRec + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-	const u32 bodyOff0 = sTask[0].bodyOff;
-	const u32 rdA0 = (regAB0 & 0xFFFFu) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB0 & 0xFFFFu), wrA0 = (regAB0 & 0xFFFFu) == CL_LOCAL_STATIC ? sinkRec : rdA0;
-	const u32 rdB0 = (regAB0 >> 16) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB0 >> 16), wrB0 = (regAB0 >> 16) == CL_LOCAL_STATIC ? sinkRec : rdB0;
-	const u32 rdA1 = (regAB1 & 0xFFFFu) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB1 & 0xFFFFu), wrA1 = (regAB1 & 0xFFFFu) == CL_LOCAL_STATIC ? sinkRec : rdA1;
-	const u32 rdB1 = (regAB1 >> 16) == CL_LOCAL_STATIC ? zeroRec : bodyOff0 + 2u * (regAB1 >> 16), wrB1 = (regAB1 >> 16) == CL_LOCAL_STATIC ? sinkRec : rdB1;
-	const u32 rowOff0 = __builtin_amdgcn_readfirstlane(sTask[0].rowOff), rowCap0 = __builtin_amdgcn_readfirstlane(sTask[0].rowCap), first0 = __builtin_amdgcn_readfirstlane(sTask[0].first);
-	// the workgroup's second task, if it has at most one manifold per lane: this lane's manifold of it (position = lane)
-	const bool second = !JOINTS && numTasks > 1u && !sTask[1].inRegs && sTask[1].count <= CLS_LANES;
-	u32 s2KE = 0xFFFFFFFFu, s2rdA = zeroRec, s2wrA = sinkRec, s2rdB = zeroRec, s2wrB = sinkRec, s2rowBase = 0; float4 s2Sh = make_float4(0.f, 0.f, 0.f, 0.f);
-	if (second && tid < sTask[1].count)
+	for (u32 i = tid; i < CLQ_ZERO_FLOAT4S; i += CLS_LANES) lds[zeroBase + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+	__syncthreads();
+	// the first task's contacts in registers: set s of this lane's quad holds contact position s * CLQ_QUADS + quad
+	QuadRow rows[SETS]; u32 addr[SETS];
 	{
-		const u32 slot = sTask[1].first + tid, ab = A.mLocal[slot], key = A.mKeySorted[slot], extra = A.mExtra[slot], off1 = sTask[1].bodyOff;
-		s2KE = key | (extra << 10); s2Sh = A.rowShared[slot]; s2rowBase = tid + extra;
-		if ((ab & 0xFFFFu) != CL_LOCAL_STATIC) { s2rdA = off1 + 2u * (ab & 0xFFFFu); s2wrA = s2rdA; }
-		if ((ab >> 16) != CL_LOCAL_STATIC) { s2rdB = off1 + 2u * (ab >> 16); s2wrB = s2rdB; }
+		const ClLocal& L = sTask[0];
+#pragma unroll
+		for (u32 s = 0; s < SETS; ++s)
+		{
+			const u32 p = s * CLQ_QUADS + quad;
+			rows[s].dT = rows[s].aT = rows[s].dN = rows[s].aN = v3(0.f, 0.f, 0.f); rows[s].mT = rows[s].mN = rows[s].bias = rows[s].friction = rows[s].lamN = rows[s].lamT = 0.f; addr[s] = sinkRec;
+			if (p < L.regContacts) { u32 slot, kk; clBuildQuadRow(rows[s], addr[s], L, A, lds, p, q, zeroBase + 2u * quad, slot, kk); }
+		}
 	}
-	const u32 rowOff1 = second ? __builtin_amdgcn_readfirstlane(sTask[1].rowOff) : 0u, rowCap1 = second ? __builtin_amdgcn_readfirstlane(sTask[1].rowCap) : 0u, first1 = second ? __builtin_amdgcn_readfirstlane(sTask[1].first) : 0u;
-	// first of the register task's trailing colours that one wave runs without barriers (see the colour loop)
-	u32 tailStart0 = sTask[0].numColors;
-	if (sTask[0].inRegs && sTask[0].serialStart > 0u) { const u32 lastBlock = (sTask[0].serialStart - 1u) >> 6; while (tailStart0 > 0u && (sTask[0].colorStart[tailStart0 - 1u] >> 6) == lastBlock) --tailStart0; }
-	tailStart0 = __builtin_amdgcn_readfirstlane(tailStart0);
-	u32 tailStart1 = second ? sTask[1].numColors : 0u;
-	if (second && sTask[1].serialStart > 0u) { const u32 lastBlock = (sTask[1].serialStart - 1u) >> 6; while (tailStart1 > 0u && (sTask[1].colorStart[tailStart1 - 1u] >> 6) == lastBlock) --tailStart1; }
-	tailStart1 = __builtin_amdgcn_readfirstlane(tailStart1);
+	// every other contact of the workgroup's tasks: its four lane rows in LDS while there is room
+	for (u32 k = 0; k < numTasks; ++k)
+	{
+		const ClLocal& L = sTask[k];
+		for (u32 i = quad; i < L.numContacts - L.regContacts; i += CLQ_QUADS)
+		{
+			QuadRow r; u32 a, slot, kk;
+			clBuildQuadRow(r, a, L, A, lds, L.regContacts + i, q, zeroBase + 2u * quad, slot, kk);
+			if (i < L.rowCap) clStoreQuadRow(lds + L.rowOff + i * CLQ_ROW_FLOAT4S, q, r, a);
+			else clStoreQuadRow(A.rowScratch + (size_t)(L.scratchBase + i - L.rowCap) * CLQ_ROW_FLOAT4S, q, r, a);
+		}
+	}
+	// The last colours of a task hold a handful of contacts (the busiest body's last rows).  Those of the first task whose positions all
+	// fall into ONE block of 16 positions belong to one wave (16 quads of one register set): that wave runs them back to back, in
+	// program order, without the workgroup barrier in between (LDS serves a wave's accesses in order).  tailStart0 = first such
+	// colour, tailSet = their register set, myTail = this lane's colour among them (255: none).
+	u32 tailStart0 = sTask[0].numColors, tailSet = 0, myTail = 255u;
+	{
+		const ClLocal& L = sTask[0];
+		const u32 endPos = L.colorStart[L.numColors];
+		if (L.numColors && endPos && endPos <= L.regContacts)
+		{
+			const u32 blk = (endPos - 1u) >> 4;
+			while (tailStart0 > 0u && (L.colorStart[tailStart0 - 1u] >> 4) == blk) --tailStart0;
+			if (L.numColors - tailStart0 < 2u) tailStart0 = L.numColors;
+			else
+			{
+				tailSet = L.colorStart[tailStart0] / CLQ_QUADS;
+				const u32 p = tailSet * CLQ_QUADS + quad;
+				if (p >= L.colorStart[tailStart0] && p < endPos) { myTail = tailStart0; while (L.colorStart[myTail + 1u] <= p) ++myTail; }
+			}
+		}
+		tailStart0 = __builtin_amdgcn_readfirstlane(tailStart0); tailSet = __builtin_amdgcn_readfirstlane(tailSet);
+	}
 	// this lane's joint (first task only, phase 0): class, update record, the two bodies as LDS addresses and as global ids (inverse inertia)
+	const u32 bodyOff0 = sTask[0].bodyOff;
 	u32 jClass = 0xFFFFFFFFu, jType = 0, jA = 0, jB = 0, jRdA = zeroRec, jWrA = sinkRec, jRdB = zeroRec, jWrB = sinkRec; float* jRec = nullptr;
 	const u32 numJoints0 = (JOINTS && sTask[0].phase == 0u) ? sTask[0].numJoints : 0u;
 	if (JOINTS && tid < numJoints0)
@@ -1128,8 +1141,40 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 	if (trace && tid == 0)
 	{
 		trace[15 * 32 + 1] = wall_clock64();
-		for (u32 k = 0; k < numTasks && k < 5u; ++k) { trace[15 * 32 + 2 + 4 * k] = sTask[k].count; trace[15 * 32 + 3 + 4 * k] = sTask[k].numColors; trace[15 * 32 + 4 + 4 * k] = sTask[k].numShared; trace[15 * 32 + 5 + 4 * k] = sTask[k].phase | (sTask[k].numBodies << 8) | ((u64)sTask[k].rowCap << 32); }
+		for (u32 k = 0; k < numTasks && k < 5u; ++k) { trace[15 * 32 + 2 + 4 * k] = sTask[k].count; trace[15 * 32 + 3 + 4 * k] = sTask[k].numColors; trace[15 * 32 + 4 + 4 * k] = sTask[k].numShared; trace[15 * 32 + 5 + 4 * k] = sTask[k].phase | (sTask[k].numBodies << 8) | ((u64)sTask[k].numContacts << 32); }
 	}
+
+	// One step = the contacts at positions [cs, end) of a task (one colour, or one contact of the serial tail).  Positions below the
+	// task's regContacts: register set position / CLQ_QUADS of quad position % CLQ_QUADS; beyond: rows from LDS / the scratch.  The
+	// colour loops below are written SET BY SET (a colour's positions are consecutive, so the colours that begin in set S are a run
+	// of the loop; one that reaches beyond set S + 1 is cut into two steps), so that the code of a step names its one or two
+	// register sets statically: no dispatch, and nothing of the other sets passes through the loop.
+#define CLQ_SOLVE_SET(S_, CS_, END_) if ((S_) < SETS) { const u32 pos = (S_) * CLQ_QUADS + quad; if (pos >= (CS_) && pos < (END_)) { float4 b = lds[addr[(S_) < SETS ? (S_) : 0u]]; V3 x = v3f4(b); clSolveQuad(rows[(S_) < SETS ? (S_) : 0u], x); lds[addr[(S_) < SETS ? (S_) : 0u]] = make_float4(x.x, x.y, x.z, b.w); } }
+#define CLQ_SOLVE_ROWS(CS_, END_) \
+	for (u32 p = max((CS_), regC) + quad; p < (END_); p += CLQ_QUADS) \
+	{ \
+		const u32 i = p - regC; \
+		QuadRow r; u32 a; \
+		float4* P = lds + rowOff + i * CLQ_ROW_FLOAT4S; \
+		float4* S = A.rowScratch + (size_t)(scratchBase + i - rowCap) * CLQ_ROW_FLOAT4S; \
+		if (i < rowCap) clLoadQuadRow(r, a, P, q); else clLoadQuadRow(r, a, S, q); \
+		float4 b = lds[a]; V3 x = v3f4(b); clSolveQuad(r, x); lds[a] = make_float4(x.x, x.y, x.z, b.w); \
+		if (q == 0u) { if (i < rowCap) ((float2*)(P + 13))[0] = make_float2(r.lamN, r.lamT); else ((float2*)(S + 13))[0] = make_float2(r.lamN, r.lamT); } \
+	}
+#define CLQ_ADVANCE(END_) \
+	__syncthreads(); \
+	if (stamp && c < 63u && (END_) == csNext) { trace[5 * 32 + 1 + c] = clock64(); trace[7 * 32 + c] = csNext - L.colorStart[c]; } \
+	if ((END_) == csNext) { csCur = csNext; csNext = __builtin_amdgcn_readfirstlane(csAfter); ++c; } else csCur = (END_);
+#define CLQ_SET_LOOP(S_) \
+	if ((S_) < SETS) while (c < mainColors && csCur < min(regC, ((S_) + 1u) * CLQ_QUADS)) \
+	{ \
+		const u32 csAfter = L.colorStart[c + 2u]; /* (requested now, needed at the next colour: the LDS round trip hides behind this step) */ \
+		const u32 end = min(csNext, ((S_) + 2u) * CLQ_QUADS), endReg = min(end, regC); \
+		CLQ_SOLVE_SET(S_, csCur, endReg) \
+		if (end > ((S_) + 1u) * CLQ_QUADS) { CLQ_SOLVE_SET((S_) + 1u, csCur, endReg) if (end > regC) { CLQ_SOLVE_ROWS(csCur, end) } } \
+		CLQ_ADVANCE(end) \
+	}
+	static_assert(CLQ_SETS == 8u, "the colour loop below names eight sets");
 
 	// ---- iterations ----
 	bool aborted = false;
@@ -1143,7 +1188,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 			// acquire the bodies other phases also touch.  The sweep is periodic: a task's bodies come back about one iteration
 			// period after they came back last time, so the workgroup sleeps through most of the previous wait before it polls (the
 			// polls are uncached loads through the fabric: 50k lanes polling all the time slow every hand-over down); then every lane
-			// polls the tagged first halves of up to four bodies per pass, all loads in flight together, and fetches the second half
+			// polls the tagged halves of up to two bodies per pass, all loads in flight together, and fetches the second half
 			// (stored before the first) once the tag has arrived.
 			{
 				if (k == 0 && lastWait > 64u && it > A.itBegin + 1u)
@@ -1152,41 +1197,41 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 					while (wall_clock64() < until) __builtin_amdgcn_s_sleep(8);
 				}
 				const u32 rel = it - A.itBegin;
-				for (u32 base = 0; base < L.numShared; base += 4u * CLS_LANES)
+				for (u32 base = 0; base < L.numShared; base += 2u * CLS_LANES)
 				{
-					u32 gid[4], want[4]; bool pend[4]; bool any = false;
+					u32 gid[2], want[2]; bool pend[2]; bool any = false;
 #pragma unroll
-					for (u32 q = 0; q < 4; ++q)
+					for (u32 qq = 0; qq < 2; ++qq)
 					{
-						u32 l = base + q * CLS_LANES + tid;
-						pend[q] = false; gid[q] = 0; want[q] = 0;
+						u32 l = base + qq * CLS_LANES + tid;
+						pend[qq] = false; gid[qq] = 0; want[qq] = 0;
 						if (l >= L.numShared) continue;
 						u32 ti = info[3 * l + 1], deg = ti & 0xFFu, rank = ti >> 8;
 						if (rel == 0u && rank == 0u) continue; // first user of the launch: the prologue's copy of vel is current
-						gid[q] = info[3 * l + 2]; want[q] = A.epoch + rel * deg + rank; pend[q] = true; any = true;
+						gid[qq] = info[3 * l + 2]; want[qq] = A.epoch + rel * deg + rank; pend[qq] = true; any = true;
 					}
 					u32 spins = 0;
 					while (any)
 					{
-						u32x4 h0[4], h1[4];
+						u32x4 h0[2], h1[2];
 						asm volatile("" ::: "memory");
 #pragma unroll
-						for (u32 q = 0; q < 4; ++q)
-							if (pend[q]) { h0[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, gid[q] * 32u, 0, 16); h1[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, gid[q] * 32u + 16u, 0, 16); }
+						for (u32 qq = 0; qq < 2; ++qq)
+							if (pend[qq]) { h0[qq] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, gid[qq] * 32u, 0, 16); h1[qq] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, gid[qq] * 32u + 16u, 0, 16); }
 						any = false;
 #pragma unroll
-						for (u32 q = 0; q < 4; ++q)
+						for (u32 qq = 0; qq < 2; ++qq)
 						{
-							if (!pend[q]) continue;
-							if (h0[q].w == want[q] && h1[q].w == want[q]) // each half carries its own tag
+							if (!pend[qq]) continue;
+							if (h0[qq].w == want[qq] && h1[qq].w == want[qq]) // each half carries its own tag
 							{
-								u32 l = base + q * CLS_LANES + tid;
+								u32 l = base + qq * CLS_LANES + tid;
 								float invMass = lds[L.bodyOff + 2 * l].w; // constant over the launch
-								lds[L.bodyOff + 2 * l] = make_float4(__uint_as_float(h0[q].x), __uint_as_float(h0[q].y), __uint_as_float(h0[q].z), invMass);
-								lds[L.bodyOff + 2 * l + 1] = make_float4(__uint_as_float(h1[q].x), __uint_as_float(h1[q].y), __uint_as_float(h1[q].z), 0.f);
-								pend[q] = false;
+								lds[L.bodyOff + 2 * l] = make_float4(__uint_as_float(h0[qq].x), __uint_as_float(h0[qq].y), __uint_as_float(h0[qq].z), invMass);
+								lds[L.bodyOff + 2 * l + 1] = make_float4(__uint_as_float(h1[qq].x), __uint_as_float(h1[qq].y), __uint_as_float(h1[qq].z), 0.f);
+								pend[qq] = false;
 							}
-							any = any || pend[q];
+							any = any || pend[qq];
 						}
 						if (any)
 						{
@@ -1220,91 +1265,41 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 					__syncthreads();
 				}
 			}
-			// colours
-			if (L.inRegs)
+			// the contacts, colour by colour (a colour = one row solve per quad), then the serial tail one contact per step
 			{
-				const u32 col0 = (regKE0 & 0x3FFu) >> 2, col1 = (regKE1 & 0x3FFu) >> 2; // 255 = no manifold: matches no colour
-				const u32 numColors = __builtin_amdgcn_readfirstlane(L.numColors), serialStart = __builtin_amdgcn_readfirstlane(L.serialStart), taskCount = __builtin_amdgcn_readfirstlane(L.count);
+				const u32 numColors = __builtin_amdgcn_readfirstlane(L.numColors), serialStart = __builtin_amdgcn_readfirstlane(L.serialStart), numContacts = __builtin_amdgcn_readfirstlane(L.numContacts);
+				// (what a step needs of the task record, in scalar registers: read from LDS once per turn, not behind every barrier)
+				const u32 regC = __builtin_amdgcn_readfirstlane(L.regContacts), rowOff = __builtin_amdgcn_readfirstlane(L.rowOff), rowCap = __builtin_amdgcn_readfirstlane(L.rowCap), scratchBase = __builtin_amdgcn_readfirstlane(L.scratchBase);
 				const bool stamp = trace && tid == 0 && it == A.itBegin + 10u && k == 0;
 				if (stamp) trace[5 * 32] = clock64();
-				// The last colours hold a handful of manifolds (the busiest body's last users).  Those whose positions all fall into
-				// ONE 64-position block belong to one wave (and one register set): that wave runs them back to back, in program
-				// order, without the workgroup barrier in between (LDS serves a wave's accesses in order).
-				const u32 tailStart = tailStart0;
-				for (u32 c = 0; c < tailStart; ++c)
+				const u32 mainColors = (k == 0u) ? tailStart0 : numColors;
+				u32 c = 0, csCur = __builtin_amdgcn_readfirstlane(L.colorStart[0]), csNext = __builtin_amdgcn_readfirstlane(L.colorStart[1]);
+				CLQ_SET_LOOP(0) CLQ_SET_LOOP(1) CLQ_SET_LOOP(2) CLQ_SET_LOOP(3) CLQ_SET_LOOP(4) CLQ_SET_LOOP(5) CLQ_SET_LOOP(6) CLQ_SET_LOOP(7)
+				while (c < mainColors) // colours that lie entirely beyond the register sets (a task that is not the workgroup's first, or larger than the sets)
 				{
-					if (col0 == c) clSolveReg(lds, A, rdA0, wrA0, rdB0, wrB0, regKE0, regSh0, regRow0, rowOff0, rowCap0, first0 + tid);
-					if (col1 == c) clSolveReg(lds, A, rdA1, wrA1, rdB1, wrB1, regKE1, regSh1, regRow1, rowOff0, rowCap0, first0 + tid + CLS_LANES);
-					__syncthreads();
-					if (stamp) { trace[5 * 32 + 1 + c] = clock64(); trace[7 * 32 + c] = L.colorStart[c + 1] - L.colorStart[c]; }
+					const u32 csAfter = L.colorStart[c + 2u];
+					CLQ_SOLVE_ROWS(csCur, csNext)
+					CLQ_ADVANCE(csNext)
 				}
-				if (tailStart < numColors)
+				if (mainColors < numColors) // the first task's trailing colours: one wave, no workgroup barrier in between
 				{
-					if (col0 >= tailStart && col0 < numColors)
-						for (u32 c = tailStart; c < numColors; ++c)
-						{
-							if (col0 == c) clSolveReg(lds, A, rdA0, wrA0, rdB0, wrB0, regKE0, regSh0, regRow0, rowOff0, rowCap0, first0 + tid);
-							__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-						}
-					if (col1 >= tailStart && col1 < numColors)
-						for (u32 c = tailStart; c < numColors; ++c)
-						{
-							if (col1 == c) clSolveReg(lds, A, rdA1, wrA1, rdB1, wrB1, regKE1, regSh1, regRow1, rowOff0, rowCap0, first0 + tid + CLS_LANES);
-							__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-						}
+#define CLQ_TAIL(S_) case S_: if ((S_) < SETS && myTail != 255u) for (u32 ct = mainColors; ct < numColors; ++ct) { if (myTail == ct) { float4 b = lds[addr[(S_) < SETS ? (S_) : 0u]]; V3 x = v3f4(b); clSolveQuad(rows[(S_) < SETS ? (S_) : 0u], x); lds[addr[(S_) < SETS ? (S_) : 0u]] = make_float4(x.x, x.y, x.z, b.w); } __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); } break;
+					switch (tailSet) { CLQ_TAIL(0) CLQ_TAIL(1) CLQ_TAIL(2) CLQ_TAIL(3) CLQ_TAIL(4) CLQ_TAIL(5) CLQ_TAIL(6) CLQ_TAIL(7) default: break; }
+#undef CLQ_TAIL
 					__syncthreads();
-					if (stamp) for (u32 c = tailStart; c < numColors; ++c) { trace[5 * 32 + 1 + c] = clock64(); trace[7 * 32 + c] = L.colorStart[c + 1] - L.colorStart[c]; }
+					if (stamp) for (u32 ct = mainColors; ct < numColors && ct < 63u; ++ct) { trace[5 * 32 + 1 + ct] = clock64(); trace[7 * 32 + ct] = L.colorStart[ct + 1u] - L.colorStart[ct]; }
 				}
-				for (u32 sp = serialStart; sp < taskCount; ++sp) // the serial tail (manifolds that found no colour below 64): one per step
+				for (u32 sp = serialStart; sp < numContacts; ++sp) // the serial tail (manifolds that found no colour run below 64): one contact per step
 				{
-					if (tid == sp) clSolveReg(lds, A, rdA0, wrA0, rdB0, wrB0, regKE0, regSh0, regRow0, rowOff0, rowCap0, first0 + tid);
-					if (tid + CLS_LANES == sp) clSolveReg(lds, A, rdA1, wrA1, rdB1, wrB1, regKE1, regSh1, regRow1, rowOff0, rowCap0, first0 + tid + CLS_LANES);
-					__syncthreads();
-				}
-			}
-			else if (second && k == 1u)
-			{
-				const u32 col = (s2KE & 0x3FFu) >> 2; // 255 = no manifold
-				const u32 numColors = __builtin_amdgcn_readfirstlane(L.numColors), serialStart = __builtin_amdgcn_readfirstlane(L.serialStart), taskCount = __builtin_amdgcn_readfirstlane(L.count);
-				for (u32 c = 0; c < tailStart1; ++c)
-				{
-					if (col == c) clSolveLds(lds, A, s2rdA, s2wrA, s2rdB, s2wrB, s2KE, s2Sh, s2rowBase, rowOff1, rowCap1, first1 + tid);
-					__syncthreads();
-				}
-				if (tailStart1 < numColors) // the trailing colours inside one wave, as in the register task
-				{
-					if (col >= tailStart1 && col < numColors)
-						for (u32 c = tailStart1; c < numColors; ++c)
-						{
-							if (col == c) clSolveLds(lds, A, s2rdA, s2wrA, s2rdB, s2wrB, s2KE, s2Sh, s2rowBase, rowOff1, rowCap1, first1 + tid);
-							__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-						}
-					__syncthreads();
-				}
-				for (u32 sp = serialStart; sp < taskCount; ++sp) // the serial tail: one manifold per step
-				{
-					if (tid == sp) clSolveLds(lds, A, s2rdA, s2wrA, s2rdB, s2wrB, s2KE, s2Sh, s2rowBase, rowOff1, rowCap1, first1 + tid);
-					__syncthreads();
-				}
-			}
-			else
-			{
-				for (u32 c = 0; c < L.numColors; ++c)
-				{
-					for (u32 i = L.colorStart[c] + tid; i < L.colorStart[c + 1]; i += CLS_LANES)
+					if (sp < regC)
 					{
-						float4 m0 = lds[L.metaOff + 2 * i], sh = lds[L.metaOff + 2 * i + 1];
-						clSolveManifold<false>(lds, L, A, i, __float_as_uint(m0.x), __float_as_uint(m0.y), sh, noRow);
+						switch (sp / CLQ_QUADS)
+						{
+							case 0: CLQ_SOLVE_SET(0u, sp, sp + 1u) break; case 1: CLQ_SOLVE_SET(1u, sp, sp + 1u) break; case 2: CLQ_SOLVE_SET(2u, sp, sp + 1u) break; case 3: CLQ_SOLVE_SET(3u, sp, sp + 1u) break;
+							case 4: CLQ_SOLVE_SET(4u, sp, sp + 1u) break; case 5: CLQ_SOLVE_SET(5u, sp, sp + 1u) break; case 6: CLQ_SOLVE_SET(6u, sp, sp + 1u) break; default: CLQ_SOLVE_SET(7u, sp, sp + 1u) break;
+						}
 					}
-					__syncthreads();
-				}
-				for (u32 s = L.serialStart; s < L.count; ++s)
-				{
-					if (tid == 0)
-					{
-						float4 m0 = lds[L.metaOff + 2 * s], sh = lds[L.metaOff + 2 * s + 1];
-						clSolveManifold<false>(lds, L, A, s, __float_as_uint(m0.x), __float_as_uint(m0.y), sh, noRow);
-					}
+					else { CLQ_SOLVE_ROWS(sp, sp + 1u) }
 					__syncthreads();
 				}
 			}
@@ -1342,38 +1337,29 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 			float4 b1 = lds[L.bodyOff + 2 * l + 1];
 			A.vel[2 * g] = lds[L.bodyOff + 2 * l]; A.vel[2 * g + 1] = make_float4(b1.x, b1.y, b1.z, 0.f);
 		}
-		if (L.inRegs)
+		if (q == 0u) // (a quad's four lanes hold the same impulses)
 		{
-#define CL_STORE_REG(R_, KE_, ROW_) \
-			{ \
-				u32 i = tid + (R_) * CLS_LANES; \
-				if (i < L.count) \
-				{ \
-					u32 slot = L.first + i, count = 4u - (KE_ & 3u), extra = KE_ >> 10; \
-					A.rowLambda[slot] = ROW_.lam; \
-					for (u32 kk = 1; kk < count; ++kk) \
-					{ \
-						u32 row = extra + kk - 1u; \
-						if (row < L.rowCap) A.rowLambda[(size_t)kk * A.rowCap + slot] = clLoadLambdaLds(lds, L.rowOff, L.rowCap, row); \
-					} \
-				} \
-			}
-			CL_STORE_REG(0u, regKE0, regRow0)
-			CL_STORE_REG(1u, regKE1, regRow1)
-#undef CL_STORE_REG
-		}
-		else for (u32 i = tid; i < L.count; i += CLS_LANES)
-		{
-			u32 slot = L.first + i;
-			u32 keyExtra = __float_as_uint(lds[L.metaOff + 2 * i].y);
-			u32 count = 4u - (keyExtra & 3u), extra = keyExtra >> 10;
-			for (u32 kk = 0; kk < count; ++kk)
+			if (k == 0)
 			{
-				u32 row = i + extra + kk;
-				if (row < L.rowCap) A.rowLambda[(size_t)kk * A.rowCap + slot] = clLoadLambdaLds(lds, L.rowOff, L.rowCap, row);
+#pragma unroll
+				for (u32 s = 0; s < SETS; ++s)
+				{
+					const u32 p = s * CLQ_QUADS + quad;
+					if (p < L.regContacts) { const u32 e = A.cEntry[(size_t)4u * L.first + p]; A.rowLambda[(size_t)(e >> 12) * A.rowCap + L.first + (e & 0xFFFu)] = make_float2(rows[s].lamN, rows[s].lamT); }
+				}
+			}
+			for (u32 i = quad; i < L.numContacts - L.regContacts; i += CLQ_QUADS)
+			{
+				const u32 e = A.cEntry[(size_t)4u * L.first + L.regContacts + i];
+				const float4 lam = i < L.rowCap ? lds[L.rowOff + i * CLQ_ROW_FLOAT4S + 13u] : A.rowScratch[(size_t)(L.scratchBase + i - L.rowCap) * CLQ_ROW_FLOAT4S + 13u];
+				A.rowLambda[(size_t)(e >> 12) * A.rowCap + L.first + (e & 0xFFFu)] = make_float2(lam.x, lam.y);
 			}
 		}
 	}
+#undef CLQ_SET_LOOP
+#undef CLQ_ADVANCE
+#undef CLQ_SOLVE_ROWS
+#undef CLQ_SOLVE_SET
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1381,7 +1367,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 // ---------------------------------------------------------------------------------------------------------------
 static size_t clColorLdsBytes()
 {
-	return sizeof(u32) * (2 * CL_HASH_SIZE + (CL_TASK_MAX_BODIES + 1) + 5 * CL_TASK_MAX_MANIFOLDS + 264 + CL_MAX_JOINT_CLASSES + 1) + sizeof(u64) * (CL_TASK_MAX_BODIES + 1);
+	return sizeof(u32) * (2 * CL_HASH_SIZE + (CL_TASK_MAX_BODIES + 1) + 5 * CL_TASK_MAX_MANIFOLDS + 264 + CL_MAX_JOINT_CLASSES + 1 + CL_SERIAL_COLOR + 2) + sizeof(u64) * (CL_TASK_MAX_BODIES + 1);
 }
 
 bool cluster_solves_joints(const World& w) { return w.clJointsInCluster && w.useClusterJoints; }
@@ -1418,10 +1404,10 @@ void launch_cluster_build(World& w, u32 numPairs)
 	{ const u32 P = CL_MAX_PARTS;
 	w.clKeys.ensure((size_t)P * nb, w.stream); w.clKeysSorted.ensure((size_t)P * nb, w.stream); w.clVals.ensure((size_t)P * nb, w.stream); w.clSorted.ensure((size_t)P * nb, w.stream);
 	w.clRank.ensure((size_t)P * nb1, w.stream); w.clSharedSlot.ensure((size_t)CL_MAX_PHASES * nb1, w.stream); w.clWsum.ensure(P * nb1, w.stream); w.clCum.ensure(nb1, w.stream); w.clPhaseMask.ensure(nb1, w.stream); }
-	w.clTaskKey.ensure(w.pairCap, w.stream); w.clTaskPos.ensure(w.pairCap, w.stream); w.clPre.ensure(w.pairCap, w.stream); w.clLocal.ensure(w.pairCap, w.stream); w.clExtra.ensure(w.pairCap, w.stream); w.clRankInfo.ensure(w.pairCap, w.stream);
+	w.clTaskKey.ensure(w.pairCap, w.stream); w.clTaskPos.ensure(w.pairCap, w.stream); w.clPre.ensure(w.pairCap, w.stream); w.clLocal.ensure(w.pairCap, w.stream); w.clEntry.ensure(4 * w.pairCap, w.stream);
 	const u32 totalKeys = CL_MAX_PHASES * CL_MAX_TASKS;
 	w.clTaskCount.ensure(totalKeys * CL_SUBCOUNTERS + 6u * CL_REMAIN_SUBS, w.stream); w.clTaskStart.ensure(totalKeys * CL_SUBCOUNTERS + 1, w.stream);
-	w.clTasks.ensure((size_t)totalKeys * sizeof(ClTask), w.stream); w.clBodyList.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream); w.clBodyUsers.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream);
+	w.clTasks.ensure((size_t)totalKeys * sizeof(ClTask), w.stream); w.clBodyList.ensure((size_t)totalKeys * CL_BODY_STRIDE, w.stream);
 	if (w.lastError) return;
 
 	dim3 bgrid((nb + 255) / 256), block(256), mgrid((numPairs + 255) / 256);
@@ -1446,7 +1432,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 	}
 	w.clusterSortAge++;
 	// tasks
-	const u32 parts = w.clusterParts;
+	const u32 parts = w.useComponents ? std::min(w.clusterParts, CL_MAX_PARTS - 1u) : w.clusterParts; // curve phases (the component phase comes on top)
 	u32 clearItems = std::max<u32>((u32)(CL_MAX_PARTS * nb1), totalKeys * CL_SUBCOUNTERS + 6u * CL_REMAIN_SUBS);
 	const bool withJoints = cluster_solves_joints(w);
 	const u32* rep = withJoints ? w.clRep.p : nullptr;
@@ -1455,7 +1441,10 @@ void launch_cluster_build(World& w, u32 numPairs)
 	w.clJointTask.ensure(std::max(nj, 1u), w.stream); w.clJointPos.ensure(std::max(nj, 1u), w.stream); w.clJointList.ensure(std::max(nj, 1u), w.stream); w.clTaskJoints.ensure(std::max(nj, 1u), w.stream);
 	w.clJointClassStart.ensure((size_t)CL_MAX_TASKS * (CL_MAX_JOINT_CLASSES + 2u), w.stream);
 	if (w.lastError) return;
-	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.clJointCount.p, w.dCounters.p);
+	w.clCompLabel.ensure(nb1, w.stream); w.clLeftList.ensure(w.pairCap, w.stream);
+	if (w.lastError) return;
+	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.clJointCount.p, w.dCounters.p, w.clCompLabel.p);
+	u32* leftList = w.useComponents ? w.clLeftList.p : nullptr; const u32 leftCap = (u32)w.pairCap;
 	const u32 maxTasks = std::min<u32>(CL_MAX_TASKS / CL_TASKS_PER_PHASE, w.clusterBlocks) - std::min<u32>(8u, w.clusterBlocks / 8u); // per phase, with a margin for the chunks' rounding
 	w.clChunk.ensure((size_t)CL_MAX_PARTS * nb1, w.stream);
 	if (w.lastError) return;
@@ -1471,7 +1460,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 			u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
 			prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
 			hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, p ? weightLater : weight0, maxTasks, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
-				w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, p == 0 ? rep : nullptr);
+				w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, p == 0 ? rep : nullptr, leftList, leftCap);
 			if (p == 0 && nj) // (cum still holds phase 0's scan)
 				hipLaunchKernelGGL(k_cl_joint_assign, dim3((nj + 255) / 256), block, 0, w.stream, nj, nb, weight0, maxTasks, w.clJointTable.p, w.clRank.p, rep, w.clCum.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
 			if (w.useChunkCache)
@@ -1483,21 +1472,30 @@ void launch_cluster_build(World& w, u32 numPairs)
 	{
 		const u32 cached = std::min(parts, w.chunkCachedPhases);
 		hipLaunchKernelGGL(k_cl_assign_cached, mgrid, block, 0, w.stream, w.dCounters.p, nb, parts, cached, withJoints ? 1u : 0u, w.actIds.p, w.clChunk.p,
-			w.clRank.p + (size_t)std::min(cached, CL_MAX_PARTS - 1) * nb1, w.clWsum.p + (size_t)std::min(cached, CL_MAX_PARTS - 1) * nb1, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p);
+			w.clRank.p + (size_t)std::min(cached, CL_MAX_PARTS - 1) * nb1, w.clWsum.p + (size_t)std::min(cached, CL_MAX_PARTS - 1) * nb1, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, leftList, leftCap);
 		if (nj) hipLaunchKernelGGL(k_cl_joint_assign_cached, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clChunk.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p);
 		for (u32 p = cached; p < parts; ++p) // the later phases: the per-step pipeline on what is left
 		{
 			u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
 			prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
 			hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, p ? w.clusterTaskWeightLater : w.clusterTaskWeight, maxTasks, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
-				w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, (const u32*)nullptr);
+				w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, (const u32*)nullptr, leftList, leftCap);
 		}
+	}
+	// what the curve phases left over: whole connected components to the tasks of one more phase (index = parts)
+	if (leftList && parts < CL_MAX_PARTS)
+	{
+		u32* compWeight = w.clWsum.p + (size_t)(CL_MAX_PARTS - 1) * nb1; // (the last curve's weight sums are not in use: zeroed by k_cl_clear)
+		for (u32 r = 0; r < CL_COMP_ROUNDS; ++r) hipLaunchKernelGGL(k_cl_comp_round, dim3(CL_COMP_BLOCKS), block, 0, w.stream, w.dCounters.p, nb, leftCap, w.clLeftList.p, w.actIds.p, w.clCompLabel.p);
+		hipLaunchKernelGGL(k_cl_comp_weights, dim3(CL_COMP_BLOCKS), block, 0, w.stream, w.dCounters.p, nb, leftCap, w.clLeftList.p, w.actIds.p, w.clCompLabel.p, compWeight);
+		hipLaunchKernelGGL(k_cl_comp_assign, dim3(CL_COMP_BLOCKS), block, 0, w.stream, w.dCounters.p, nb, parts, w.clusterTaskWeightLater, leftCap, w.clLeftList.p, w.actIds.p, w.clCompLabel.p, compWeight,
+			w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p);
 	}
 	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, parts, w.clTaskCount.p, w.clTaskStart.p, nj ? w.clJointCount.p : (u32*)nullptr, nj ? w.clJointStart.p : (u32*)nullptr);
 	if (nj) hipLaunchKernelGGL(k_cl_joint_scatter, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTask.p, w.clJointPos.p, w.clJointStart.p, w.clJointList.p);
 	hipLaunchKernelGGL(k_cl_scatter, mgrid, block, 0, w.stream, w.dCounters.p, w.clTaskKey.p, w.clTaskPos.p, w.clTaskStart.p, w.clPre.p);
 	hipLaunchKernelGGL(k_cl_color, dim3(w.clusterBlocks), dim3(CL_LANES), clColorLdsBytes(), w.stream, w.dCounters.p, nb, w.clTaskStart.p, w.clPre.p, w.actIds.p,
-		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.clBodyUsers.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clExtra.p, w.clRankInfo.p, w.clSharedSlot.p,
+		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clEntry.p, w.clSharedSlot.p,
 		nj ? w.clJointStart.p : (const u32*)nullptr, w.clJointList.p, w.clJointTable.p, w.clTaskJoints.p, w.clJointClassStart.p, w.flowTrace.p);
 }
 
@@ -1519,9 +1517,14 @@ void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd)
 		MI_CHECK(hipMemcpyAsync(w.dCounters.p + CTR_FLOW_STATUS, &one, sizeof(u32), hipMemcpyHostToDevice, w.stream));
 		MI_CHECK(hipStreamSynchronize(w.stream));
 	}
+	const size_t scratchContacts = std::min<size_t>(2 * w.pairCap, 512u * 1024u); // rows that fit neither the registers nor LDS (224 B each)
+	w.clRowScratch.ensure(scratchContacts * CLQ_ROW_FLOAT4S, w.stream);
+	if (w.lastError) return;
+	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CL_SCRATCH, 0, sizeof(u32), w.stream));
 	ClArgs A;
-	A.counters = w.dCounters.p; A.tasks = (const ClTask*)w.clTasks.p; A.bodyList = w.clBodyList.p; A.bodyUsers = w.clBodyUsers.p; A.phaseMask = w.clPhaseMask.p; A.sharedSlot = w.clSharedSlot.p;
-	A.mKeySorted = w.mKeySorted.p; A.mLocal = w.clLocal.p; A.mExtra = w.clExtra.p; A.mRank = w.clRankInfo.p;
+	A.rowScratch = w.clRowScratch.p; A.scratchContacts = (u32)scratchContacts;
+	A.counters = w.dCounters.p; A.tasks = (const ClTask*)w.clTasks.p; A.bodyList = w.clBodyList.p; A.phaseMask = w.clPhaseMask.p; A.sharedSlot = w.clSharedSlot.p;
+	A.mKeySorted = w.mKeySorted.p; A.mLocal = w.clLocal.p; A.cEntry = w.clEntry.p;
 	A.rowPlanes = w.rowPlanes.p; A.rowShared = w.rowShared.p; A.rowLambda = w.rowLambda.p; A.vel = w.vel.p; A.flow = w.flow.p; A.trace = w.flowTrace.p; A.predictDiv = w.clusterPredictDiv; A.pollSleep = w.clusterPollSleep;
 	A.rowCap = w.rowCap; A.nb = w.nb; A.flowBytes = (u32)(words * sizeof(u64)); A.epoch = w.flowEpoch << 16; A.itBegin = itBegin; A.itEnd = itEnd;
 	A.ldsFloat4s = w.clusterLdsBytes / 16u;

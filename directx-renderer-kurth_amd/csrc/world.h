@@ -93,6 +93,8 @@ enum
 	CTR_CL_SHARED = 430,    // statistics: bodies handed between tasks (summed over tasks)
 	CTR_CL_PHASE_COUNT = 431,// 5 words: statistics: manifolds per phase
 	CTR_CL_BBOX = 436,      // 6 words: min xyz, max xyz of the simulated bodies' centres of gravity (order-preserving integer encoding)
+	CTR_CL_LEFT = 372,      // 5 words: cluster build: manifolds left over by the curve phases (cursor of the list the component phase works on); statistics of the component phase: tasks, total weight, manifolds whose ends disagree, weight of the largest component sent to the rest task
+	CTR_CL_SCRATCH = 371,   // cluster sweep: append cursor of the global row scratch (contacts that fit neither registers nor LDS), reset before every launch
 	CTR_VALIDATE = 448,     // 2 words: non-finite values found by the debug guard (MI_PHYSICS_VALIDATE=1), first offender (stage << 28 | index)
 	CTR_CL_REMAIN = 442,    // 6 words: manifolds still unassigned when partition phase p starts ([0] unused: all active ones)
 	CTR_WORDS = 512,
@@ -183,12 +185,14 @@ struct World
 	u32 scheduleReferenceBatches(const std::vector<uint4>& ids, u32 numPositions);
 	bool useCluster = true;               // MI_PHYSICS_NO_CLUSTER=1: launch-per-colour sweep only
 	bool lastStepCluster = false, backupVelocities = false;
-	u32 clusterPredictDiv = 4, clusterPollSleep = 1, clusterBlocksLimit = 0, clusterFailStreak = 0, clusterParts = 3, clusterTaskWeight = 64u * 1200u, clusterTaskWeightLater = 64u * 560u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
+	u32 clusterPredictDiv = 4, clusterPollSleep = 1, clusterBlocksLimit = 0, clusterFailStreak = 0, clusterParts = 2, clusterTaskWeight = 64u * 1000u, clusterTaskWeightLater = 64u * 500u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
 	bool clusterPartsFixed = false;       // MI_CLUSTER_PARTS given: no adaptation
 	bool clusterSortDue = true; u32 clusterSortAge = 0, clusterSortInterval = 8, clusterSortBodies = 0; // body order along the curves: refreshed every few steps (MI_CLUSTER_SORT_INTERVAL)
 	u32 clusterLdsBytes = 0, clusterBlocks = 0, clusterCooldown = 0;
-	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clExtra, clTaskCount, clTaskStart, clBodyList, clBodyUsers, clRankInfo, clSharedSlot;
+	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clEntry, clTaskCount, clTaskStart, clBodyList, clSharedSlot; // clEntry: the contact schedule of every task (at 4 x its first manifold position): manifold position | contact << 12
 	DevBuf<uint8_t> clTasks;
+	DevBuf<float4> clRowScratch;
+	DevBuf<u32> clCompLabel, clLeftList; bool useComponents = true; // the component phase (MI_CLUSTER_NO_COMPONENTS=1: curve phases + rest task only)
 	DevBuf<u32> clChunk; u32 clChunkParts = 0, clChunkJointVersion = ~0u; bool clChunkWithJoints = false, useChunkCache = true; u32 chunkHeadroomPercent = 10, chunkCachedPhases = CL_MAX_PARTS; // chunk of every body per phase, kept between re-sorts (MI_CLUSTER_NO_CHUNK_CACHE=1: the full partition pipeline every step)
 	// joints inside the cluster sweep: island representative per body (jointed bodies must share a task), the joints of all types in
 	// (type, colour) order {type | class << 8, index in the type's colour-sorted arrays, body a, body b}, and the per-step lists

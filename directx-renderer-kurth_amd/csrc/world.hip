@@ -58,9 +58,10 @@ World::World(int dev) : device(dev)
 	useWarmColoring = getenv("MI_PHYSICS_NO_WARM_COLORING") == nullptr;
 	if (const char* e = getenv("MI_COLOR_FULL_INTERVAL")) fullColoringInterval = (u32)atoi(e);
 	if (const char* e = getenv("MI_FLOW_TEST_ABORT")) flowTestAbortStep = (u32)atoi(e); // tests: make the cluster sweep of that internal step give up
+	if (getenv("MI_CLUSTER_NO_COMPONENTS")) { useComponents = false; clusterParts = 3; } else clusterPartsFixed = true; // with the component phase: two curve phases + the components, no adaptation
 	if (const char* e = getenv("MI_CLUSTER_PARTS")) { clusterParts = std::min<u32>(CL_MAX_PARTS, std::max(1, atoi(e))); clusterPartsFixed = true; }
 	if (const char* e = getenv("MI_CLUSTER_SORT_INTERVAL")) clusterSortInterval = (u32)std::max(1, atoi(e));
-	if (const char* e = getenv("MI_CLUSTER_TASK")) { clusterTaskWeight = 64u * (u32)std::max(16, atoi(e)); clusterTaskWeightLater = std::min(clusterTaskWeight, 64u * 560u); }  // manifolds per task
+	if (const char* e = getenv("MI_CLUSTER_TASK")) { clusterTaskWeight = 64u * (u32)std::max(16, atoi(e)); clusterTaskWeightLater = std::min(clusterTaskWeight, clusterTaskWeightLater); }  // manifolds per task
 	if (getenv("MI_PHYSICS_REPLAY")) replayReferenceOrder = true;
 	if (getenv("MI_CLUSTER_NO_CHUNK_CACHE")) useChunkCache = false;
 	if (const char* e = getenv("MI_CLUSTER_CHUNK_PHASES")) chunkCachedPhases = (u32)std::min(4, std::max(1, atoi(e)));
@@ -648,10 +649,11 @@ void World::recoverFlow()
 	// with one more partition phase; anything else = a lane timed out (GPU shared with another persistent kernel): stay away for a while
 	u32 why = hCounters[CTR_FLOW_STATUS];
 	if (getenv("MI_CLUSTER_DEBUG"))
-		fprintf(stderr, "[mi_physics] step %u: cluster sweep gave up: status %u, build status %u, parts %u, tasks %u %u %u %u %u, manifolds %u %u %u %u %u (active %u), remain %u %u %u %u %u\n", stats.numInternalSteps, why,
+		fprintf(stderr, "[mi_physics] step %u: cluster sweep gave up: status %u, build status %u, parts %u, tasks %u %u %u %u %u, manifolds %u %u %u %u %u (active %u), remain %u %u %u %u %u; components: listed %u tasks %u weight %u ends disagree %u largest too-big %u\n", stats.numInternalSteps, why,
 			hCounters[CTR_CL_STATUS], clusterParts, hCounters[CTR_CL_NUM_TASKS], hCounters[CTR_CL_NUM_TASKS + 1], hCounters[CTR_CL_NUM_TASKS + 2], hCounters[CTR_CL_NUM_TASKS + 3], hCounters[CTR_CL_NUM_TASKS + 4],
 			hCounters[CTR_CL_PHASE_COUNT], hCounters[CTR_CL_PHASE_COUNT + 1], hCounters[CTR_CL_PHASE_COUNT + 2], hCounters[CTR_CL_PHASE_COUNT + 3], hCounters[CTR_CL_PHASE_COUNT + 4], hCounters[CTR_NUM_ACTIVE],
-			hCounters[CTR_CL_REMAIN + 1], hCounters[CTR_CL_REMAIN + 2], hCounters[CTR_CL_REMAIN + 3], hCounters[CTR_CL_REMAIN + 4], hCounters[CTR_CL_REMAIN + 5]);
+			hCounters[CTR_CL_REMAIN + 1], hCounters[CTR_CL_REMAIN + 2], hCounters[CTR_CL_REMAIN + 3], hCounters[CTR_CL_REMAIN + 4], hCounters[CTR_CL_REMAIN + 5],
+			hCounters[CTR_CL_LEFT], hCounters[CTR_CL_LEFT + 1], hCounters[CTR_CL_LEFT + 2], hCounters[CTR_CL_LEFT + 3], hCounters[CTR_CL_LEFT + 4]);
 	// (a world that keeps not fitting backs off: 4, 8, ... 256 steps of launch sweep between attempts)
 	if ((why & 64u) && !(why & 1u)) { clusterCooldown = std::min(256u, 4u << std::min(clusterFailStreak, 6u)); ++clusterFailStreak; if (!clusterPartsFixed && clusterParts < CL_MAX_PARTS) ++clusterParts; }
 	else clusterCooldown = 256;
@@ -718,6 +720,9 @@ void World::countPreviousStep()
 	// Partition phases of the next step: one more when the rest task is filling up (it has hard limits), one fewer when the last
 	// one found nothing to do (each costs a sort of the bodies).
 	if (had && lastStepCluster) clusterFailStreak = 0; // (a give-up never gets here: recoverFlow clears lastStepCluster)
+	if (had && lastStepCluster && (stats.numInternalSteps % 50u) == 0u && getenv("MI_CLUSTER_DEBUG"))
+		fprintf(stderr, "[mi_physics] step %u: component phase: %u manifolds left by the curve phases, %u tasks, weight %u, %u with ends in different components after the rounds, largest component sent to the rest task %u\n", stats.numInternalSteps,
+			hCounters[CTR_CL_LEFT], hCounters[CTR_CL_LEFT + 1], hCounters[CTR_CL_LEFT + 2], hCounters[CTR_CL_LEFT + 3], hCounters[CTR_CL_LEFT + 4]);
 	if (had && lastStepCluster && !clusterPartsFixed)
 	{
 		// (every phase costs a hand-over per iteration: the last partition phase is dropped as soon as what it holds would fit the rest task too)
@@ -1176,7 +1181,7 @@ int mi_snapshot_save(mi_world* world, void* buffer, uint64_t capacity)
 	if (W->lastError) return W->lastError;
 	W->refreshCounters();     // the last step is counted now (and has had its say on the number of partition phases), not at the next step:
 	W->clusterSortDue = true; // the restored world orders its bodies at its first step: so does this one at its next ...
-	if (!W->clusterPartsFixed) W->clusterParts = 3; // ... and both start from the default number of partition phases
+	if (!W->clusterPartsFixed) W->clusterParts = 3; // ... and both start from the default number of partition phases (without the component phase: with it the number is fixed)
 	W->clusterCooldown = 0; W->clusterFailStreak = 0; // ... with the cluster sweep on
 	if (!buffer || capacity < out.bytes.size()) { W->fail(MI_ERR_CAPACITY, "mi_snapshot_save: buffer too small (ask mi_snapshot_size)"); return MI_ERR_CAPACITY; }
 	memcpy(buffer, out.bytes.data(), out.bytes.size());

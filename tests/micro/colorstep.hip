@@ -39,10 +39,11 @@ MI_DEV void solveRow2(ContactRow& r, V3 n, float friction, float invMassA, float
 #ifdef ROW2
 #define solveRow(R_, N_, F_, MA_, MB_, VA_, WA_, VB_, WB_) solveRow2(R_, N_, F_, MA_, MB_, VA_, WA_, VB_, WB_, 0.013f)
 #endif
-enum { V_FULL = 0, V_NOBARRIER = 1, V_ALLWAVES = 2, V_BARRIER_ONLY = 3, V_LDS_ONLY = 4, V_NO_LDS = 5, V_FOUR = 6, V_FOUR_PREFETCH = 7, V_QUAD_ONE = 8, V_QUAD_ALL = 9, V_LDS_R = 10, V_LDS_W = 11, V_LDS_1 = 12, V_COUNT = 13 };
+enum { V_FULL = 0, V_NOBARRIER = 1, V_ALLWAVES = 2, V_BARRIER_ONLY = 3, V_LDS_ONLY = 4, V_NO_LDS = 5, V_FOUR = 6, V_FOUR_PREFETCH = 7, V_QUAD_ONE = 8, V_QUAD_ALL = 9, V_LDS_R = 10, V_LDS_W = 11, V_LDS_1 = 12, V_QUAD_RANDOM = 13, V_QUAD_SHARED_ZERO = 14, V_COUNT = 15 };
 static const char* names[V_COUNT] = { "full: one wave solves, 8 waves barrier", "same wave every step, wave fence instead of the barrier", "all 8 waves solve every step + barrier", "barrier only",
 	"LDS round trip + barrier, no arithmetic", "arithmetic + barrier, bodies stay in registers", "4-contact manifold: rows 1-3 from LDS one after the other", "4-contact manifold: all LDS rows requested up front",
-	"QUAD: 4 lanes per contact (one body vector each), one wave active", "QUAD: all 8 waves active", "LDS: 4 x read b128 + barrier", "LDS: 4 x write b128 + barrier", "LDS: 1 read + 1 write b128 + barrier" };
+	"QUAD: 4 lanes per contact (one body vector each), one wave active", "QUAD: all 8 waves active", "LDS: 4 x read b128 + barrier", "LDS: 4 x write b128 + barrier", "LDS: 1 read + 1 write b128 + barrier",
+	"QUAD, all waves, body vectors at pseudo-random LDS addresses (bank conflicts)", "QUAD, all waves, random addresses, a third of the quads share ONE static record (same-address writes)" };
 
 MI_DEV void ldRow(ContactRow& r, const float4* lds, u32 off, u32 cap, u32 row)
 {
@@ -98,8 +99,14 @@ template <int VAR> __global__ void __launch_bounds__(512) k_step(int steps, unsi
 	{
 		bool mine = (VAR == V_ALLWAVES) ? true : (VAR == V_NOBARRIER ? wave == 0 : wave == (u32)(s & 7));
 		if (VAR == V_BARRIER_ONLY) mine = false;
-		if (VAR == V_QUAD_ALL) mine = true;
-		if (VAR == V_QUAD_ONE || VAR == V_QUAD_ALL)
+		if (VAR == V_QUAD_ALL || VAR == V_QUAD_RANDOM || VAR == V_QUAD_SHARED_ZERO) mine = true;
+		if (VAR == V_QUAD_RANDOM || VAR == V_QUAD_SHARED_ZERO)
+		{
+			u32 h = (tid >> 1) * 2654435761u + (u32)s * 40503u; h ^= h >> 15; u32 a = ((h % 2000u) * 2u) + (tid & 1u);
+			if (VAR == V_QUAD_SHARED_ZERO && ((tid >> 2) % 3u) == 0u && (tid & 2u)) a = 4000u + (tid & 1u);
+			float4 b = lds[a]; V3 x = v3f4(b); solveQuad(qr, sh.w, x); lds[a] = make_float4(x.x, x.y, x.z, b.w);
+		}
+		else if (VAR == V_QUAD_ONE || VAR == V_QUAD_ALL)
 		{
 			if (mine) { float4 b = lds[qAddr]; V3 x = v3f4(b); solveQuad(qr, sh.w, x); lds[qAddr] = make_float4(x.x, x.y, x.z, b.w); }
 		}
@@ -162,7 +169,7 @@ int main(int argc, char** argv)
 	{
 		run<V_FULL>(blocks, steps, dOut, dSink); run<V_NOBARRIER>(blocks, steps, dOut, dSink); run<V_ALLWAVES>(blocks, steps, dOut, dSink); run<V_BARRIER_ONLY>(blocks, steps, dOut, dSink);
 		run<V_LDS_ONLY>(blocks, steps, dOut, dSink); run<V_NO_LDS>(blocks, steps, dOut, dSink); run<V_FOUR>(blocks, steps, dOut, dSink); run<V_FOUR_PREFETCH>(blocks, steps, dOut, dSink);
-		run<V_QUAD_ONE>(blocks, steps, dOut, dSink); run<V_QUAD_ALL>(blocks, steps, dOut, dSink); run<V_LDS_R>(blocks, steps, dOut, dSink); run<V_LDS_W>(blocks, steps, dOut, dSink); run<V_LDS_1>(blocks, steps, dOut, dSink);
+		run<V_QUAD_ONE>(blocks, steps, dOut, dSink); run<V_QUAD_ALL>(blocks, steps, dOut, dSink); run<V_LDS_R>(blocks, steps, dOut, dSink); run<V_LDS_W>(blocks, steps, dOut, dSink); run<V_LDS_1>(blocks, steps, dOut, dSink); run<V_QUAD_RANDOM>(blocks, steps, dOut, dSink); run<V_QUAD_SHARED_ZERO>(blocks, steps, dOut, dSink);
 	}
 	return 0;
 }
