@@ -53,7 +53,7 @@ class Stats(C.Structure):
                 ("msIntegrate", C.c_float), ("msTotal", C.c_float),
                 ("avgContacts", C.c_float), ("avgCollisions", C.c_float), ("avgColors", C.c_float), ("avgBroadphaseOverlaps", C.c_float), ("avgFlowProbes", C.c_float),
                 ("avgSteps", C.c_uint32),
-                ("clusterTasks", C.c_uint32 * 5), ("clusterManifolds", C.c_uint32 * 5), ("clusterSharedBodies", C.c_uint32), ("clusterParts", C.c_uint32)]
+                ("clusterTasks", C.c_uint32 * 5), ("clusterManifolds", C.c_uint32 * 5), ("clusterSharedBodies", C.c_uint32), ("clusterParts", C.c_uint32), ("numNarrowphaseRedone", C.c_uint32)]
 
     def asdict(self):
         return {n: (list(getattr(self, n)) if n in ("clusterTasks", "clusterManifolds") else getattr(self, n)) for n, _ in self._fields_}

@@ -251,12 +251,12 @@ void launch_broadphase_count(World& w)
 	hipLaunchKernelGGL(k_finish_pair_count, dim3(1), dim3(64), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.dCounters.p, w.sapPartial.p, (nc + 255) / 256, w.stats.numInternalSteps & 1u);
 }
 
-void launch_broadphase_write(World& w, u32 numPairs)
+void launch_broadphase_write(World& w, u32 numPairs, bool slabOverflow)
 {
 	u32 nc = w.nc;
 	if (!nc || !numPairs) return;
 	hipLaunchKernelGGL(k_pairs_pack, dim3((u32)(((size_t)nc * PAIR_SLAB + 255) / 256)), dim3(256), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.pairSlab.p, w.pairs.p, (u32)w.pairCap);
-	if (w.hCounters[CTR_PAIR_OVERFLOW]) // some colliders have more than PAIR_SLAB partners: those (only) repeat their traversal, writing in place
+	if (slabOverflow) // some colliders have more than PAIR_SLAB partners: those (only) repeat their traversal, writing in place
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_WRITE>), dim3((u32)(((size_t)nc * PAIR_LANES + 255) / 256)), dim3(256), 0, w.stream, nc, w.hashTableSize - 1, w.sCellKey.p, w.sMin.p, w.sMax.p,
 			w.cellStart.p, w.cellEnd.p, w.dCounters.p, w.pairCount.p, w.pairOffset.p, w.pairs.p, (u32)w.pairCap);
 }

@@ -26,10 +26,11 @@ MI_DEV bool typeSupported(u32 t) { return t <= MI_HULL; }
 // whose box STARTS FIRST on this step's sorting axis.  Equal starts: the reference's order is that of its endpoint array (a stable
 // insertion sort carried over from earlier frames); here the lower collider index comes first.
 __global__ void __launch_bounds__(256) k_classify(const u32* __restrict__ counters, u32 nb, const uint2* __restrict__ pairs, const ColliderRec* __restrict__ colWorld, const float4* __restrict__ aabbMin, u32 stepParity,
-	u32* __restrict__ pairKey, u64* __restrict__ pairPacked)
+	u32* __restrict__ pairKey, u64* __restrict__ pairPacked, u32 numLaunched)
 {
 	u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-	if (p >= counters[CTR_NUM_PAIRS]) return;
+	if (p >= numLaunched) return;
+	if (p >= counters[CTR_NUM_PAIRS]) { pairKey[p] = KEY_INVALID; pairPacked[p] = 0ull; return; } // (the launch is sized before the host knows the pair count: the surplus sorts behind everything)
 	uint2 pr = pairs[p];
 	float4 da = colWorld[pr.x].d, db = colWorld[pr.y].d;
 	u32 tA = __float_as_uint(da.x), tB = __float_as_uint(db.x), bA = __float_as_uint(da.y), bB = __float_as_uint(db.y);
@@ -1207,7 +1208,7 @@ void launch_narrowphase(World& w, u32 numPairs)
 		return;
 	}
 	dim3 grid((numPairs + 255) / 256), block(256);
-	hipLaunchKernelGGL(k_classify, grid, block, 0, w.stream, w.dCounters.p, w.nb, w.pairs.p, w.colWorld.p, w.aabbMin.p, w.stats.numInternalSteps & 1u, w.pairKey.p, (u64*)w.pairsSorted.p + numPairs);
+	hipLaunchKernelGGL(k_classify, grid, block, 0, w.stream, w.dCounters.p, w.nb, w.pairs.p, w.colWorld.p, w.aabbMin.p, w.stats.numInternalSteps & 1u, w.pairKey.p, (u64*)w.pairsSorted.p + numPairs, numPairs);
 	// sort (bucket key, packed pair): unsorted packed pairs live in the upper half of pairsSorted, sorted ones in the lower half
 	csort_pairs_u64(w, w.pairKey.p, w.pairKeySorted.p, (const u64*)w.pairsSorted.p + numPairs, (u64*)w.pairsSorted.p, numPairs, 64);
 	hipLaunchKernelGGL(k_bucket_offsets, dim3(1), dim3(64), 0, w.stream, w.dCounters.p, w.pairKeySorted.p);
@@ -1233,11 +1234,16 @@ void launch_narrowphase(World& w, u32 numPairs)
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epa<0>), dim3(epaBlocks), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
 	if (!w.hulls.empty())
 		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_epa<1>), dim3(std::min<u32>((numPairs + EPA_WAVES_PER_BLOCK - 1) / EPA_WAVES_PER_BLOCK, (u32)(numCUs * epaPerCU[1]))), dim3(64 * EPA_WAVES_PER_BLOCK), 0, w.stream, w.dCounters.p, w.pairKeySorted.p, sortedPairs, w.colWorld.p, w.manifolds.p, w.epaList.p, w.gjkSimplex.p, w.hullInfo.p, w.hullVerts.p, listCap);
-	if (!w.fields.empty() || !w.triggers.empty())
-	{
-		PairSetView tv = { w.triggers.empty() ? nullptr : w.triggerSet[w.triggerCur].p, w.triggers.empty() ? nullptr : w.triggerSet[w.triggerCur ^ 1].p, w.triggerSetSize - 1, 64u - (u32)__builtin_ctz(w.triggerSetSize ? w.triggerSetSize : 2u) };
-		EventSink sink = { (EventRec*)w.eventRing.p, w.dCounters.p, w.eventCap, w.stats.numInternalSteps };
-		hipLaunchKernelGGL(k_zone_overlap, dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, sortedPairs, w.colWorld.p, w.hullInfo.p, w.hullVerts.p, w.nb,
-			w.fieldMask.p, w.fieldWords, tv, sink);
-	}
+}
+
+// Force fields and triggers: boolean overlap tests on the pairs behind the collision buckets (collision_narrow.cpp:2573-2593).  Not
+// part of launch_narrowphase: it enters pairs into the trigger set and raises events, so it must run exactly once per step.
+void launch_zone_overlap(World& w, u32 numPairs)
+{
+	if (!numPairs || (w.fields.empty() && w.triggers.empty())) return;
+	const u64* sortedPairs = (const u64*)w.pairsSorted.p;
+	PairSetView tv = { w.triggers.empty() ? nullptr : w.triggerSet[w.triggerCur].p, w.triggers.empty() ? nullptr : w.triggerSet[w.triggerCur ^ 1].p, w.triggerSetSize - 1, 64u - (u32)__builtin_ctz(w.triggerSetSize ? w.triggerSetSize : 2u) };
+	EventSink sink = { (EventRec*)w.eventRing.p, w.dCounters.p, w.eventCap, w.stats.numInternalSteps };
+	hipLaunchKernelGGL(k_zone_overlap, dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, sortedPairs, w.colWorld.p, w.hullInfo.p, w.hullVerts.p, w.nb,
+		w.fieldMask.p, w.fieldWords, tv, sink);
 }

@@ -127,6 +127,8 @@ struct World
 	DevBuf<uint16_t> terrainHeights; DevBuf<u32> terrainValid, terrainCounts, terrainOffsets;
 	u32 terrainSlotCap() const { return terrainChunksPerDim ? std::max(terrainMinSlots, terrainSlotsPerCollider * (u32)colliders.size()) : 0u; }
 	u32 prevTruePairs = 0;                // broadphase overlaps of the last step (prevNumPairs counts the terrain slots too)
+	bool prevSlabOverflow = false;        // CTR_PAIR_OVERFLOW of the last step
+	hipEvent_t countersEvent = nullptr;   // behind the step's asynchronous read of the counters
 	// cloth_component (cloth.h:5-60): parameters + host mirror of the particle state (authoritative until the first step; refreshed by downloadCloths)
 	struct HClothConstraint { u32 a, b; float restDistance, inverseMassSum; u32 color; };
 	struct HCloth
@@ -263,8 +265,9 @@ struct World
 // ---- launchers (one per stage; each defined next to its kernels) --------------------------------------------------
 void launch_build_colliders(World& w);
 void launch_broadphase_count(World& w);                    // grid build + pair count + scan; leaves numPairs in dCounters
-void launch_broadphase_write(World& w, u32 numPairs);
-void launch_narrowphase(World& w, u32 numPairs);
+void launch_broadphase_write(World& w, u32 numPairs, bool slabOverflow);       // slabOverflow: some collider has more partners than its slab holds (CTR_PAIR_OVERFLOW)
+void launch_narrowphase(World& w, u32 numPairs);            // numPairs may exceed the device's pair count (a launch sized before the host knows it)
+void launch_zone_overlap(World& w, u32 numPairs);           // force-field / trigger overlap tests on the classified pairs (once per step)
 void launch_integrate_forces(World& w, float dt);
 void launch_heightmap(World& w, u32 numPairs, u32 slotCap);  // terrain contacts appended after the pair manifolds (physics.cpp:1236-1249)
 void launch_cloth(World& w, float dt);                      // cloth_component::applyWindForce + simulate for every cloth (physics.cpp:1354-1358)

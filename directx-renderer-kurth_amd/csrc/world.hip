@@ -47,6 +47,7 @@ World::World(int dev) : device(dev)
 	if (dCounters.p) MI_CHECK(hipMemsetAsync(dCounters.p, 0, CTR_WORDS * sizeof(u32), stream));
 	stageEvents.resize(STAGE_RING * 6);
 	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
+	MI_CHECK(hipEventCreateWithFlags(&countersEvent, hipEventDisableTiming));
 	// The launch-per-colour sweep (the fallback solver) as plain launches: a hipGraph of its ~600 kernel nodes has to be re-instantiated
 	// whenever the number of colours changes (58 times in 260 steps of config 3, tens of ms each: 25 ms/step against 3 ms/step).
 	// MI_PHYSICS_GRAPH=1 replays it as a graph (pays off only where the colour count is stable: small resting scenes).
@@ -92,6 +93,7 @@ World::~World()
 	rowLambda.release(); rowIds.release(); tempStorage.release(); actIds.release(); epaList.release(); gjkSimplex.release(); pairSlab.release(); simMask.release();
 	for (auto& js : joints) { js.dPods.release(); js.dPairs.release(); js.dUpdate.release(); }
 	for (auto& e : stageEvents) if (e) (void)hipEventDestroy(e);
+	if (countersEvent) (void)hipEventDestroy(countersEvent);
 	if (hCounters) (void)hipHostFree(hCounters);
 	if (stream) (void)hipStreamDestroy(stream);
 	g_currentWorld = nullptr;
@@ -767,7 +769,26 @@ int World::stepInternal(float dt, u32 iters)
 	launch_build_colliders(*this);
 	launch_validate(*this, 0, 0);
 	launch_broadphase_count(*this);
-	readCounters(*this);                                   // sync #1: number of overlapping pairs
+	// The step's one host read: the pair count (it sizes buffers and launches), with it the previous step's counts and status words.
+	// The copy is asynchronous; while it is on its way the device is given work that does not need the host's knowledge of the
+	// count: the pair list and the narrowphase, launched for the previous step's count plus a margin (their kernels take the
+	// real count from the device and ignore the surplus).  If the count turns out larger than that, or a collider outgrew its pair
+	// slab this step, both are launched again with the right size — a repeated narrowphase in the rare step where the pile jumps.
+	MI_CHECK(hipMemcpyAsync(hCounters, dCounters.p, CTR_WORDS * sizeof(u32), hipMemcpyDeviceToHost, stream));
+	MI_CHECK(hipEventRecord(countersEvent, stream));
+	u32 guess = 0; bool early = false;
+	if (prevTruePairs && !validate)
+	{
+		guess = prevTruePairs + prevTruePairs / 8u + 4096u;
+		if ((size_t)guess + terrainSlotCap() <= pairCap)
+		{
+			early = true;
+			launch_broadphase_write(*this, guess, prevSlabOverflow);
+			if (T) MI_CHECK(hipEventRecord(ev[1], stream));
+			launch_narrowphase(*this, guess);
+		}
+	}
+	MI_CHECK(hipEventSynchronize(countersEvent));          // sync #1: number of overlapping pairs
 	if (hCounters[CTR_FLOW_STATUS])                        // the cluster sweep of the previous step gave up
 	{
 		flowPending = false;
@@ -775,6 +796,7 @@ int World::stepInternal(float dt, u32 iters)
 		launch_build_colliders(*this);                     // ... and this step's start, which ran on the stale poses
 		launch_broadphase_count(*this);
 		readCounters(*this);
+		early = false;
 	}
 	flowPending = false;
 	if (hCounters[CTR_VALIDATE])                           // the debug guard found NaN / Inf in the previous step (or in this step's colliders)
@@ -787,14 +809,20 @@ int World::stepInternal(float dt, u32 iters)
 	countPreviousStep();                                   // the counters just read hold the previous step's colour / contact counts
 	if (hCounters[CTR_TERRAIN_OVERFLOW]) { fail(MI_ERR_CAPACITY, "more terrain contacts than manifold slots: contacts were dropped (raise MI_TERRAIN_SLOTS_PER_COLLIDER)"); return lastError; }
 	const u32 truePairs = hCounters[CTR_NUM_PAIRS];
+	const bool slabOverflow = hCounters[CTR_PAIR_OVERFLOW] != 0u;
 	const u32 numPairs = truePairs + terrainSlotCap();     // bound on the manifold slots of the step: pair slots + room for the terrain contacts
+	if (early && (truePairs > guess || (slabOverflow && !prevSlabOverflow))) { early = false; stats.numNarrowphaseRedone++; }
 	ensurePairBuffers(*this, numPairs);
 	ensureEventBuffers(numPairs);
 	if (lastError) return lastError;                       // an allocation failed: nothing of this step may touch the pair buffers
-	launch_broadphase_write(*this, truePairs);
-	if (T) MI_CHECK(hipEventRecord(ev[1], stream));
-
-	launch_narrowphase(*this, truePairs);
+	if (!early)
+	{
+		launch_broadphase_write(*this, truePairs, slabOverflow);
+		if (T) MI_CHECK(hipEventRecord(ev[1], stream));
+		launch_narrowphase(*this, truePairs);
+	}
+	launch_zone_overlap(*this, early ? guess : truePairs);
+	prevSlabOverflow = slabOverflow;
 	launch_heightmap(*this, truePairs, numPairs);          // physics.cpp:1236-1249
 	launch_trigger_events(*this);                          // physics.cpp:1255 (handleNonCollisionInteractions)
 	launch_validate(*this, 1, numPairs);

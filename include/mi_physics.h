@@ -70,6 +70,7 @@ typedef struct mi_stats
 	/* cluster contact sweep of the last step (all 0 after a launch-sweep step): tasks and manifolds per phase ([4] = the rest task),
 	 * bodies handed between tasks (summed over the tasks that touch them), partition phases prepared */
 	uint32_t clusterTasks[5], clusterManifolds[5], clusterSharedBodies, clusterParts;
+	uint32_t numNarrowphaseRedone;           /* steps whose pair list + narrowphase, launched before the host knew the pair count, had to be launched again (the count jumped by more than 12 %) */
 } mi_stats;
 
 /* ---- lifetime ------------------------------------------------------------------------------------------------ */

@@ -18,5 +18,5 @@ for i in range(starts[0], starts[-1]):
     key = n.split("(")[0].split("<")[0][-40:]
     per[key] += (e - s)
 print("last %d steps: span %.3f ms/step, kernels busy %.3f ms/step, idle %.3f ms/step (%.1f %%)" % (steps, span / steps / 1e6, busy / steps / 1e6, (span - busy) / steps / 1e6, 100.0 * (span - busy) / span))
-for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:12]:
+for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:40]:
     print("  %-42s %8.1f us/step" % (k, v / steps / 1e3))
