@@ -136,7 +136,7 @@ MI_DEV float buildCollider(u32 i, u32 nb, const ColliderRec* __restrict__ colLoc
 // variances agree to within that float sum's rounding).
 __global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
 	const float4* __restrict__ colStaticPose, const uint8_t* __restrict__ simMask, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax,
-	u32* __restrict__ counters, u32* __restrict__ cellStart, u32 hashTableSize, const float4* __restrict__ hullInfo, double* __restrict__ sapPartial)
+	u32* __restrict__ counters, u32* __restrict__ cellStart, u32* __restrict__ cellCount, u32 hashTableSize, const float4* __restrict__ hullInfo, double* __restrict__ sapPartial)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	float e = (i < nc) ? buildCollider(i, nb, colLocal, pose, colStaticPose, simMask, colWorld, aabbMin, aabbMax, hullInfo) : 0.f;
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const C
 	__syncthreads();
 	if (threadIdx.x == 0 && sMax) atomicMax(&counters[CTR_CELL_SIZE], sMax);
 	if (threadIdx.x < 7) sapPartial[(size_t)blockIdx.x * 7 + threadIdx.x] = ((sAcc[0][threadIdx.x] + sAcc[1][threadIdx.x]) + sAcc[2][threadIdx.x]) + sAcc[3][threadIdx.x];
-	for (u32 h = i; h < hashTableSize; h += gridDim.x * blockDim.x) cellStart[h] = 0xFFFFFFFFu; // EMPTY_CELL
+	for (u32 h = i; h < hashTableSize + 3u; h += gridDim.x * blockDim.x) { if (h < hashTableSize) cellStart[h] = 0xFFFFFFFFu; cellCount[h] = 0u; } // EMPTY_CELL; bucket sizes (+ the 'large' and 'simulated elsewhere' buckets)
 }
 
 void launch_build_colliders(World& w)
@@ -169,7 +169,7 @@ void launch_build_colliders(World& w)
 	w.sapPartial.ensure((size_t)blocks * 7, w.stream);
 	if (w.lastError) return;
 	hipLaunchKernelGGL(k_build_colliders, dim3(blocks), dim3(256), 0, w.stream, w.nc, w.nb, w.colLocal.p, w.pose.p, w.colStaticPose.p,
-		w.simMask.p, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.cellStart.p, w.hashTableSize, w.hullInfo.p, w.sapPartial.p);
+		w.simMask.p, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.cellStart.p, w.cellCount.p, w.hashTableSize, w.hullInfo.p, w.sapPartial.p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

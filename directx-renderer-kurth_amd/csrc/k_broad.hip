@@ -33,7 +33,7 @@ MI_DEV bool aabbOverlap(float4 amin, float4 amax, float4 bmin, float4 bmax)
 }
 
 __global__ void __launch_bounds__(256) k_cell_assign(u32 nc, u32 hashMask, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
-	u32* __restrict__ counters, u32* __restrict__ hashKey, u32* __restrict__ sortIdx)
+	u32* __restrict__ counters, u32* __restrict__ hashKey, u32* __restrict__ cellCount)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i == 0) { counters[CTR_FIRST_LARGE] = 0xFFFFFFFFu; counters[CTR_FIRST_INACTIVE] = 0xFFFFFFFFu; counters[CTR_PAIR_OVERFLOW] = 0u; } // "none" until k_gather_sorted / k_pairs say otherwise
@@ -48,7 +48,28 @@ __global__ void __launch_bounds__(256) k_cell_assign(u32 nc, u32 hashMask, const
 	else if (e > maxExtent) { h = hashMask + 1; } // large: sorts behind every grid cell
 	else { h = hashCell(packCell(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell)), hashMask); }
 	hashKey[i] = h;
-	sortIdx[i] = i;
+	atomicAdd(&cellCount[h], 1u); // bucket sizes (cleared by k_build_colliders): the order by bucket is a counting sort, see k_cell_place
+}
+
+// Order of the colliders by cell bucket = what a stable sort by hash key would give (bucket after bucket, inside a bucket by
+// collider index), without a sort: bucket sizes (k_cell_assign) -> exclusive scan = first position of every bucket -> every collider
+// takes a slot of its bucket in arrival order (atomic cursor: cellBase[h] ends up at the bucket's END) -> k_cell_rank puts the few
+// colliders of a bucket in index order, so that the order, and with it the pair list, repeats from run to run.  (rocPRIM's merge
+// sort of the 100k keys was 12 launches, 70 us per step.)  The bucket of the colliders simulated elsewhere keeps arrival order: nobody visits it.
+__global__ void __launch_bounds__(256) k_cell_place(u32 nc, const u32* __restrict__ hashKey, u32* __restrict__ cellBase, u32* __restrict__ tmpIdx)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nc) tmpIdx[atomicAdd(&cellBase[hashKey[i]], 1u)] = i;
+}
+__global__ void __launch_bounds__(256) k_cell_rank(u32 nc, u32 hashMask, const u32* __restrict__ hashKey, const u32* __restrict__ cellBase, const u32* __restrict__ cellCount, const u32* __restrict__ tmpIdx,
+	u32* __restrict__ hashSorted, u32* __restrict__ idxSorted)
+{
+	u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nc) return;
+	const u32 i = tmpIdx[t], h = hashKey[i], end = cellBase[h], start = end - cellCount[h];
+	u32 rank = t - start;
+	if (h != hashMask + 2u) { rank = 0; for (u32 u = start; u < end; ++u) rank += tmpIdx[u] < i ? 1u : 0u; }
+	hashSorted[start + rank] = h; idxSorted[start + rank] = i;
 }
 
 __global__ void __launch_bounds__(256) k_gather_sorted(u32 nc, u32 hashMask, const u32* __restrict__ hashSorted, const u32* __restrict__ idxSorted,
@@ -240,8 +261,10 @@ void launch_broadphase_count(World& w)
 	dim3 grid((nc + 255) / 256), block(256);
 	u32 H = w.hashTableSize, mask = H - 1;
 	// cell size (max extent) and the cleared cell table come out of k_build_colliders
-	hipLaunchKernelGGL(k_cell_assign, grid, block, 0, w.stream, nc, mask, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.hashKey.p, w.sortIdx.p);
-	prim_sort_pairs_u32(w, w.hashKey.p, w.hashKeySorted.p, w.sortIdx.p, w.sortIdxSorted.p, nc, log2ceil(H) + 1);
+	hipLaunchKernelGGL(k_cell_assign, grid, block, 0, w.stream, nc, mask, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.hashKey.p, w.cellCount.p);
+	prim_exclusive_scan_u32(w, w.cellCount.p, w.cellBase.p, H + 3);
+	hipLaunchKernelGGL(k_cell_place, grid, block, 0, w.stream, nc, w.hashKey.p, w.cellBase.p, w.sortIdx.p);
+	hipLaunchKernelGGL(k_cell_rank, grid, block, 0, w.stream, nc, mask, w.hashKey.p, w.cellBase.p, w.cellCount.p, w.sortIdx.p, w.hashKeySorted.p, w.sortIdxSorted.p);
 	hipLaunchKernelGGL(k_gather_sorted, grid, block, 0, w.stream, nc, mask, w.hashKeySorted.p, w.sortIdxSorted.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p,
 		w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p);
 	w.pairSlab.ensure((size_t)nc * PAIR_SLAB, w.stream);

@@ -166,6 +166,7 @@ struct World
 	// spatial slab (mi_slab_*): ownership code per body, stamp of the last refresh of a ghost, this rank's interval
 	DevBuf<uint8_t> slabCode; DevBuf<u32> slabFresh; u32 slabRank = 0, slabSize = 0, slabAxis = 0, slabStamp = 0; float slabLo = 0.f, slabHi = 0.f, slabMargin = 0.f;
 	// broadphase
+	DevBuf<u32> cellCount, cellBase;      // colliders per cell bucket (+ 'large', 'simulated elsewhere'), first / end position of every bucket in the sorted order
 	DevBuf<u32> hashKey, hashKeySorted, sortIdx, sortIdxSorted, cellStart, cellEnd, largeFlag, largeScan, largeList, pairCount, pairOffset;
 	DevBuf<u64> sCellKey; DevBuf<float4> sMin, sMax;
 	DevBuf<double> sapPartial;            // per workgroup of k_build_colliders: sum of the AABB centres (3), of their squares (3), colliders counted (1)

@@ -363,7 +363,7 @@ void World::upload()
 	hashKey.ensure(ncap, stream); hashKeySorted.ensure(ncap, stream); sortIdx.ensure(ncap, stream); sortIdxSorted.ensure(ncap, stream);
 	sCellKey.ensure(ncap, stream); sMin.ensure(ncap, stream); sMax.ensure(ncap, stream); pairCount.ensure(ncap + 1, stream); pairOffset.ensure(ncap + 1, stream);
 	hashTableSize = std::max(1024u, nextPow2(2 * nc));
-	cellStart.ensure(hashTableSize, stream); cellEnd.ensure(hashTableSize, stream);
+	cellStart.ensure(hashTableSize, stream); cellEnd.ensure(hashTableSize, stream); cellCount.ensure(hashTableSize + 4, stream); cellBase.ensure(hashTableSize + 4, stream);
 
 	if (nb)
 	{
