@@ -134,20 +134,23 @@ MI_DEV float buildCollider(u32 i, u32 nb, const ColliderRec* __restrict__ colLoc
 // collision_broad.cpp:374-376; reduced in a fixed order by k_finish_pair_count, in double: the reference adds them up in float, one
 // collider after the other, which no parallel sum reproduces bit for bit — the two can disagree on the axis only where two
 // variances agree to within that float sum's rounding).
-__global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
+__global__ void __launch_bounds__(256) k_build_colliders(u32 nb, const u32* __restrict__ activeCols, const ColliderRec* __restrict__ colLocal, const float4* __restrict__ pose,
 	const float4* __restrict__ colStaticPose, const uint8_t* __restrict__ simMask, ColliderRec* __restrict__ colWorld, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax,
 	u32* __restrict__ counters, u32* __restrict__ cellStart, u32* __restrict__ cellCount, u32 hashTableSize, const float4* __restrict__ hullInfo, double* __restrict__ sapPartial)
 {
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	float e = (i < nc) ? buildCollider(i, nb, colLocal, pose, colStaticPose, simMask, colWorld, aabbMin, aabbMax, hullInfo) : 0.f;
+	const u32 gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+	const u32 n = counters[CTR_ACTIVE_COLS]; // colliders of this world's simulated bodies + the static ones (k_active_*): the launch is sized from the last known count, the loop takes any
+	float e = 0.f;
 	double acc[7] = { 0., 0., 0., 0., 0., 0., 0. };
-	if (i < nc)
+	for (u32 a = gid; a < n; a += stride)
 	{
+		const u32 i = activeCols[a];
+		e = fmaxf(e, buildCollider(i, nb, colLocal, pose, colStaticPose, simMask, colWorld, aabbMin, aabbMax, hullInfo));
 		float4 mn = aabbMin[i], mx = aabbMax[i];
-		if (mn.x <= mx.x) // (an empty box = a body simulated elsewhere: not a collider of this world's sweep)
+		if (mn.x <= mx.x)
 		{
 			float cx = (mn.x + mx.x) * 0.5f, cy = (mn.y + mx.y) * 0.5f, cz = (mn.z + mx.z) * 0.5f; // bounding_box::getCenter
-			acc[0] = cx; acc[1] = cy; acc[2] = cz; acc[3] = (double)cx * cx; acc[4] = (double)cy * cy; acc[5] = (double)cz * cz; acc[6] = 1.;
+			acc[0] += cx; acc[1] += cy; acc[2] += cz; acc[3] += (double)cx * cx; acc[4] += (double)cy * cy; acc[5] += (double)cz * cz; acc[6] += 1.;
 		}
 	}
 	for (int o = 32; o > 0; o >>= 1) { e = fmaxf(e, __shfl_xor(e, o)); for (int k = 0; k < 7; ++k) acc[k] += __shfl_xor(acc[k], o); }
@@ -159,104 +162,194 @@ __global__ void __launch_bounds__(256) k_build_colliders(u32 nc, u32 nb, const C
 	__syncthreads();
 	if (threadIdx.x == 0 && sMax) atomicMax(&counters[CTR_CELL_SIZE], sMax);
 	if (threadIdx.x < 7) sapPartial[(size_t)blockIdx.x * 7 + threadIdx.x] = ((sAcc[0][threadIdx.x] + sAcc[1][threadIdx.x]) + sAcc[2][threadIdx.x]) + sAcc[3][threadIdx.x];
-	for (u32 h = i; h < hashTableSize + 3u; h += gridDim.x * blockDim.x) { if (h < hashTableSize) cellStart[h] = 0xFFFFFFFFu; cellCount[h] = 0u; } // EMPTY_CELL; bucket sizes (+ the 'large' and 'simulated elsewhere' buckets)
+	for (u32 h = gid; h < hashTableSize + 3u; h += stride) { if (h < hashTableSize) cellStart[h] = 0xFFFFFFFFu; cellCount[h] = 0u; } // EMPTY_CELL; bucket sizes (+ the 'large' and 'simulated elsewhere' buckets)
 }
+
+u32 active_grid(u32 estimate, u32 total) { return (u32)((std::min<u64>(total, (u64)estimate + estimate / 8u + 2048u) + 255u) / 256u); } // workgroups of 256 for a kernel that strides over an active list
 
 void launch_build_colliders(World& w)
 {
 	if (!w.nc) return;
-	const u32 blocks = (w.nc + 255) / 256;
+	launch_active_lists(w);
+	const u32 blocks = std::max(1u, active_grid(w.estActiveCols, w.nc));
 	w.sapPartial.ensure((size_t)blocks * 7, w.stream);
 	if (w.lastError) return;
-	hipLaunchKernelGGL(k_build_colliders, dim3(blocks), dim3(256), 0, w.stream, w.nc, w.nb, w.colLocal.p, w.pose.p, w.colStaticPose.p,
+	w.sapBlocks = blocks;
+	hipLaunchKernelGGL(k_build_colliders, dim3(blocks), dim3(256), 0, w.stream, w.nb, w.actCols.p, w.colLocal.p, w.pose.p, w.colStaticPose.p,
 		w.simMask.p, w.colWorld.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.cellStart.p, w.cellCount.p, w.hashTableSize, w.hullInfo.p, w.sapPartial.p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Active lists.  A world may simulate a subset of its bodies (a spatial slab of a multi-GPU world simulates what it owns plus ghosts,
+// a deleted body is switched off): the per-body and per-collider kernels of a step walk LISTS of the simulated bodies and of their
+// colliders (+ the static colliders), so a slab's step costs what its own bodies cost, not what the whole world's would.  The lists
+// are in ascending index order (so every later order, and with it every result, is the same as without them) and rebuilt when the
+// simulate mask may have changed: 256 items per workgroup -> counts, one workgroup scans the counts, the first kernel's twin scatters.
+// ---------------------------------------------------------------------------------------------------------------
+MI_DEV bool activeItem(u32 item, u32 nb, u32 nc, const uint8_t* simMask, const u32* colBody)
+{
+	if (item < nb) return simMask[item] != 0;
+	const u32 c = item - nb;
+	if (c >= nc) return false;
+	const u32 body = colBody[c];
+	return body >= nb || simMask[body] != 0;
+}
+// items [0, nb) = bodies, [nbPad, nbPad + nc) = colliders (nbPad = nb rounded up to the workgroup size, so that a workgroup holds one kind)
+__global__ void __launch_bounds__(256) k_active_count(u32 nb, u32 nbPad, u32 nc, const uint8_t* __restrict__ simMask, const u32* __restrict__ colBody, u32* __restrict__ blockCount)
+{
+	const u32 g = blockIdx.x * 256u + threadIdx.x;
+	const bool on = g < nbPad ? (g < nb && simMask[g] != 0) : activeItem(nb + (g - nbPad), nb, nc, simMask, colBody);
+	const u32 c = (u32)__syncthreads_count(on);
+	if (threadIdx.x == 0) blockCount[blockIdx.x] = c;
+}
+__global__ void __launch_bounds__(1024) k_active_scan(u32 bodyBlocks, u32 totalBlocks, const u32* __restrict__ blockCount, u32* __restrict__ blockBase, u32* __restrict__ counters)
+{
+	__shared__ u32 part[1024];
+	__shared__ u32 sBodies;
+	const u32 t = threadIdx.x, per = (totalBlocks + 1023u) / 1024u;
+	// two independent exclusive scans laid end to end: the body blocks, then the collider blocks
+	u32 sum = 0;
+	for (u32 k = 0; k < per; ++k) { u32 b = t * per + k; if (b < totalBlocks) sum += blockCount[b]; }
+	part[t] = sum;
+	__syncthreads();
+	for (u32 o = 1; o < 1024u; o <<= 1) { u32 v = (t >= o) ? part[t - o] : 0u; __syncthreads(); part[t] += v; __syncthreads(); }
+	u32 run = part[t] - sum;
+	for (u32 k = 0; k < per; ++k) { u32 b = t * per + k; if (b < totalBlocks) { if (b == bodyBlocks) sBodies = run; blockBase[b] = run; run += blockCount[b]; } }
+	__syncthreads();
+	if (t == 1023u) { const u32 bodies = bodyBlocks < totalBlocks ? sBodies : part[1023]; counters[CTR_ACTIVE_BODIES] = bodies; counters[CTR_ACTIVE_COLS] = part[1023] - bodies; }
+}
+__global__ void __launch_bounds__(256) k_active_scatter(u32 nb, u32 nbPad, u32 nc, u32 bodyBlocks, const uint8_t* __restrict__ simMask, const u32* __restrict__ colBody, const u32* __restrict__ blockBase,
+	u32* __restrict__ actBodies, u32* __restrict__ actCols)
+{
+	const u32 g = blockIdx.x * 256u + threadIdx.x;
+	const bool isBody = g < nbPad;
+	const bool on = isBody ? (g < nb && simMask[g] != 0) : activeItem(nb + (g - nbPad), nb, nc, simMask, colBody);
+	__shared__ u32 waveCount[4];
+	const u64 m = __ballot(on);
+	const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	if (lane == 0) waveCount[wv] = (u32)__popcll(m);
+	__syncthreads();
+	u32 base = blockBase[blockIdx.x];
+	for (u32 k = 0; k < wv; ++k) base += waveCount[k];
+	if (!on) return;
+	const u32 pos = base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+	if (isBody) actBodies[pos] = g; else actCols[pos - blockBase[bodyBlocks]] = g - nbPad;
+}
+void launch_active_lists(World& w)
+{
+	if (!w.activeDirty) return;
+	w.activeDirty = false;
+	const u32 nb = w.nb, nc = w.nc, nbPad = (nb + 255u) / 256u * 256u, bodyBlocks = nbPad / 256u, total = bodyBlocks + (nc + 255u) / 256u;
+	w.actBodies.ensure((size_t)nb + 1, w.stream); w.actCols.ensure((size_t)nc + 1, w.stream); w.actBlockCount.ensure(total + 1, w.stream); w.actBlockBase.ensure(total + 1, w.stream);
+	if (w.lastError || !total) return;
+	hipLaunchKernelGGL(k_active_count, dim3(total), dim3(256), 0, w.stream, nb, nbPad, nc, w.simMask.p, w.colBody.p, w.actBlockCount.p);
+	hipLaunchKernelGGL(k_active_scan, dim3(1), dim3(1024), 0, w.stream, bodyBlocks, total, w.actBlockCount.p, w.actBlockBase.p, w.dCounters.p);
+	hipLaunchKernelGGL(k_active_scatter, dim3(total), dim3(256), 0, w.stream, nb, nbPad, nc, bodyBlocks, w.simMask.p, w.colBody.p, w.actBlockBase.p, w.actBodies.p, w.actCols.p);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K8: gravity + force integration, world inertia.  140 B read + 104 B write per body.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, const float4* __restrict__ pose, const float4* __restrict__ bprops,
-	const float4* __restrict__ force, const uint8_t* __restrict__ simMask, float4* __restrict__ vel, float4* __restrict__ cog, float4* __restrict__ invIw,
+__global__ void __launch_bounds__(256) k_integrate_forces(u32 nb, float dt, const u32* __restrict__ counters, const u32* __restrict__ actBodies, const float4* __restrict__ pose, const float4* __restrict__ bprops,
+	const float4* __restrict__ force, float4* __restrict__ vel, float4* __restrict__ cog, float4* __restrict__ invIw,
 	u64* __restrict__ bodyMask, u64* __restrict__ claim, float4* __restrict__ velBackup)
 {
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > nb) return;
-	if (bodyMask) { bodyMask[i] = 0ull; claim[i] = ~0ull; claim[(size_t)nb + i] = ~0ull; } // per-body state of the colouring that follows (saves three fill launches)
-	// velBackup: the pre-solve velocities, kept in case the cluster sweep has to be redone (World::recoverFlow); written here, where
-	// every body's velocity passes through registers anyway, instead of by a copy of the whole array afterwards
-	if (i < nb && !simMask[i]) { if (velBackup) { velBackup[2 * i] = vel[2 * i]; velBackup[2 * i + 1] = vel[2 * i + 1]; } return; }
-	if (i == nb) // static dummy (physics.cpp:1279)
+	const u32 n = counters[CTR_ACTIVE_BODIES];
+	for (u32 a = blockIdx.x * blockDim.x + threadIdx.x; a <= n; a += gridDim.x * blockDim.x)
 	{
-		float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-		vel[2 * i] = z; vel[2 * i + 1] = z; cog[i] = z; invIw[3 * i] = z; invIw[3 * i + 1] = z; invIw[3 * i + 2] = z;
-		if (velBackup) { velBackup[2 * i] = z; velBackup[2 * i + 1] = z; }
-		return;
+		const u32 i = a == n ? nb : actBodies[a]; // the simulated bodies, then the static dummy
+		if (bodyMask) { bodyMask[i] = 0ull; claim[i] = ~0ull; claim[(size_t)nb + i] = ~0ull; } // per-body state of the colouring that follows (saves three fill launches)
+		if (i == nb) // static dummy (physics.cpp:1279)
+		{
+			float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+			vel[2 * i] = z; vel[2 * i + 1] = z; cog[i] = z; invIw[3 * i] = z; invIw[3 * i + 1] = z; invIw[3 * i + 2] = z;
+			if (velBackup) { velBackup[2 * i] = z; velBackup[2 * i + 1] = z; }
+			continue;
+		}
+		V3 pos = v3f4(pose[2 * i]);
+		Q4 rot = q4f4(pose[2 * i + 1]);
+		float4 p0 = bprops[5 * i], c0 = bprops[5 * i + 1], c1 = bprops[5 * i + 2], c2 = bprops[5 * i + 3], p4 = bprops[5 * i + 4];
+		V3 localCOG = v3f4(p0); float invMass = p0.w;
+		M3 I; I.m00 = c0.x; I.m10 = c0.y; I.m20 = c0.z; I.m01 = c1.x; I.m11 = c1.y; I.m21 = c1.z; I.m02 = c2.x; I.m12 = c2.y; I.m22 = c2.z;
+		float gravityFactor = p4.x, linDamp = p4.y, angDamp = p4.z;
+
+		V3 gpos = pos + rot * localCOG;
+		M3 R = quaternionToMat3(rot);
+		M3 Iw = R * I * mtranspose(R);
+
+		V3 F = v3f4(force[2 * i]), T = v3f4(force[2 * i + 1]);
+		if (invMass > 0.f) { F.y += (GRAVITY / invMass * gravityFactor); }
+		V3 linAcc = F * invMass;
+		V3 angAcc = Iw * T;
+		float4 lv = vel[2 * i], av = vel[2 * i + 1];
+		V3 v = v3f4(lv), wv = v3f4(av);
+		v += linAcc * dt;
+		wv += angAcc * dt;
+		v *= 1.f / (1.f + dt * linDamp);
+		wv *= 1.f / (1.f + dt * angDamp);
+
+		vel[2 * i] = make_float4(v.x, v.y, v.z, invMass);
+		vel[2 * i + 1] = make_float4(wv.x, wv.y, wv.z, 0.f);
+		// the pre-solve velocities, kept in case the cluster sweep has to be redone (World::recoverFlow): written here, where every
+		// simulated body's velocity passes through registers anyway (the bodies simulated elsewhere keep theirs: the restore walks the same list)
+		if (velBackup) { velBackup[2 * i] = make_float4(v.x, v.y, v.z, invMass); velBackup[2 * i + 1] = make_float4(wv.x, wv.y, wv.z, 0.f); }
+		cog[i] = make_float4(gpos.x, gpos.y, gpos.z, invMass);
+		invIw[3 * i] = make_float4(Iw.m00, Iw.m10, Iw.m20, 0.f);
+		invIw[3 * i + 1] = make_float4(Iw.m01, Iw.m11, Iw.m21, 0.f);
+		invIw[3 * i + 2] = make_float4(Iw.m02, Iw.m12, Iw.m22, 0.f);
 	}
-	V3 pos = v3f4(pose[2 * i]);
-	Q4 rot = q4f4(pose[2 * i + 1]);
-	float4 p0 = bprops[5 * i], c0 = bprops[5 * i + 1], c1 = bprops[5 * i + 2], c2 = bprops[5 * i + 3], p4 = bprops[5 * i + 4];
-	V3 localCOG = v3f4(p0); float invMass = p0.w;
-	M3 I; I.m00 = c0.x; I.m10 = c0.y; I.m20 = c0.z; I.m01 = c1.x; I.m11 = c1.y; I.m21 = c1.z; I.m02 = c2.x; I.m12 = c2.y; I.m22 = c2.z;
-	float gravityFactor = p4.x, linDamp = p4.y, angDamp = p4.z;
-
-	V3 gpos = pos + rot * localCOG;
-	M3 R = quaternionToMat3(rot);
-	M3 Iw = R * I * mtranspose(R);
-
-	V3 F = v3f4(force[2 * i]), T = v3f4(force[2 * i + 1]);
-	if (invMass > 0.f) { F.y += (GRAVITY / invMass * gravityFactor); }
-	V3 linAcc = F * invMass;
-	V3 angAcc = Iw * T;
-	float4 lv = vel[2 * i], av = vel[2 * i + 1];
-	V3 v = v3f4(lv), wv = v3f4(av);
-	v += linAcc * dt;
-	wv += angAcc * dt;
-	v *= 1.f / (1.f + dt * linDamp);
-	wv *= 1.f / (1.f + dt * angDamp);
-
-	vel[2 * i] = make_float4(v.x, v.y, v.z, invMass);
-	vel[2 * i + 1] = make_float4(wv.x, wv.y, wv.z, 0.f);
-	if (velBackup) { velBackup[2 * i] = make_float4(v.x, v.y, v.z, invMass); velBackup[2 * i + 1] = make_float4(wv.x, wv.y, wv.z, 0.f); }
-	cog[i] = make_float4(gpos.x, gpos.y, gpos.z, invMass);
-	invIw[3 * i] = make_float4(Iw.m00, Iw.m10, Iw.m20, 0.f);
-	invIw[3 * i + 1] = make_float4(Iw.m01, Iw.m11, Iw.m21, 0.f);
-	invIw[3 * i + 2] = make_float4(Iw.m02, Iw.m12, Iw.m22, 0.f);
+}
+__global__ void __launch_bounds__(256) k_restore_velocities(u32 nb, const u32* __restrict__ counters, const u32* __restrict__ actBodies, const float4* __restrict__ velBackup, float4* __restrict__ vel)
+{
+	const u32 n = counters[CTR_ACTIVE_BODIES];
+	for (u32 a = blockIdx.x * blockDim.x + threadIdx.x; a <= n; a += gridDim.x * blockDim.x)
+	{
+		const u32 i = a == n ? nb : actBodies[a];
+		vel[2 * i] = velBackup[2 * i]; vel[2 * i + 1] = velBackup[2 * i + 1];
+	}
+}
+void launch_restore_velocities(World& w)
+{
+	hipLaunchKernelGGL(k_restore_velocities, dim3(std::max(1u, active_grid(w.estActiveBodies + 1, w.nb + 1))), dim3(256), 0, w.stream, w.nb, w.dCounters.p, w.actBodies.p, w.velBackup.p, w.vel.p);
 }
 
 void launch_integrate_forces(World& w, float dt)
 {
-	hipLaunchKernelGGL(k_integrate_forces, dim3((w.nb + 1 + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.force.p,
-		w.simMask.p, w.vel.p, w.cog.p, w.invIw.p, w.bodyMask.p, w.claim.p, w.backupVelocities ? w.velBackup.p : nullptr);
+	hipLaunchKernelGGL(k_integrate_forces, dim3(std::max(1u, active_grid(w.estActiveBodies + 1, w.nb + 1))), dim3(256), 0, w.stream, w.nb, dt, w.dCounters.p, w.actBodies.p, w.pose.p, w.bprops.p, w.force.p,
+		w.vel.p, w.cog.p, w.invIw.p, w.bodyMask.p, w.claim.p, w.backupVelocities ? w.velBackup.p : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // K13: velocity integration.  Reads cog(16) + vel(32) + rot(16) + localCOG(16), writes pose(32) + clears accumulators.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_integrate_velocities(u32 nb, float dt, float4* __restrict__ pose, const float4* __restrict__ bprops,
-	const float4* __restrict__ vel, const float4* __restrict__ cog, const uint8_t* __restrict__ simMask, float4* __restrict__ force, const u32* __restrict__ flowStatus)
+__global__ void __launch_bounds__(256) k_integrate_velocities(u32 nb, float dt, const u32* __restrict__ counters, const u32* __restrict__ actBodies, float4* __restrict__ pose, const float4* __restrict__ bprops,
+	const float4* __restrict__ vel, const float4* __restrict__ cog, float4* __restrict__ force, const u32* __restrict__ flowStatus)
 {
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= nb || !simMask[i]) return;
 	if (*flowStatus) return; // the cluster sweep gave up: velocities are invalid, the host redoes the solve and this integration (World::recoverFlow)
-	Q4 grot = q4f4(pose[2 * i + 1]);
-	V3 gpos = v3f4(cog[i]);
-	V3 v = v3f4(vel[2 * i]), wv = v3f4(vel[2 * i + 1]);
-	V3 localCOG = v3f4(bprops[5 * i]);
-	Q4 deltaRot = q4(0.5f * wv.x, 0.5f * wv.y, 0.5f * wv.z, 0.f);
-	deltaRot = deltaRot * grot;
-	Q4 rotation = qnormalize(q4(grot.x + deltaRot.x * dt, grot.y + deltaRot.y * dt, grot.z + deltaRot.z * dt, grot.w + deltaRot.w * dt));
-	V3 position = gpos + v * dt;
-	V3 epos = position - rotation * localCOG;
-	pose[2 * i] = make_float4(epos.x, epos.y, epos.z, 0.f);
-	pose[2 * i + 1] = make_float4(rotation.x, rotation.y, rotation.z, rotation.w);
-	float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-	force[2 * i] = z; force[2 * i + 1] = z;
+	const u32 n = counters[CTR_ACTIVE_BODIES];
+	for (u32 a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x)
+	{
+		const u32 i = actBodies[a];
+		Q4 grot = q4f4(pose[2 * i + 1]);
+		V3 gpos = v3f4(cog[i]);
+		V3 v = v3f4(vel[2 * i]), wv = v3f4(vel[2 * i + 1]);
+		V3 localCOG = v3f4(bprops[5 * i]);
+		Q4 deltaRot = q4(0.5f * wv.x, 0.5f * wv.y, 0.5f * wv.z, 0.f);
+		deltaRot = deltaRot * grot;
+		Q4 rotation = qnormalize(q4(grot.x + deltaRot.x * dt, grot.y + deltaRot.y * dt, grot.z + deltaRot.z * dt, grot.w + deltaRot.w * dt));
+		V3 position = gpos + v * dt;
+		V3 epos = position - rotation * localCOG;
+		pose[2 * i] = make_float4(epos.x, epos.y, epos.z, 0.f);
+		pose[2 * i + 1] = make_float4(rotation.x, rotation.y, rotation.z, rotation.w);
+		float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+		force[2 * i] = z; force[2 * i + 1] = z;
+	}
 }
 
 void launch_integrate_velocities(World& w, float dt)
 {
 	if (!w.nb) return;
-	hipLaunchKernelGGL(k_integrate_velocities, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, dt, w.pose.p, w.bprops.p, w.vel.p, w.cog.p, w.simMask.p, w.force.p, w.dCounters.p + CTR_FLOW_STATUS);
+	hipLaunchKernelGGL(k_integrate_velocities, dim3(std::max(1u, active_grid(w.estActiveBodies, w.nb))), dim3(256), 0, w.stream, w.nb, dt, w.dCounters.p, w.actBodies.p, w.pose.p, w.bprops.p, w.vel.p, w.cog.p, w.force.p, w.dCounters.p + CTR_FLOW_STATUS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -294,6 +387,7 @@ __global__ void __launch_bounds__(256) k_and_mask(u32 nb, uint8_t* __restrict__ 
 void launch_and_mask(World& w)
 {
 	if (w.nb) hipLaunchKernelGGL(k_and_mask, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, w.simMask.p, w.aliveMask.p);
+	w.activeDirty = true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -408,6 +502,7 @@ void launch_slab_classify(World& w)
 {
 	if (!w.nb) return;
 	hipLaunchKernelGGL(k_slab_classify, dim3((w.nb + 255) / 256), dim3(256), 0, w.stream, w.nb, w.slabAxis, w.slabLo, w.slabHi, w.slabMargin, w.pose.p, w.aliveMask.p, w.slabCode.p, w.simMask.p, w.slabFresh.p);
+	w.activeDirty = true;
 }
 void launch_slab_pack(World& w, void* left, void* right, u32 capacity)
 {
@@ -424,4 +519,5 @@ void launch_slab_unpack(World& w, const void* left, const void* right, u32 capac
 	if (left && capacity) hipLaunchKernelGGL(k_slab_apply, grid, block, 0, w.stream, w.nb, capacity, w.slabStamp, (uint8_t)MI_SLAB_GHOST_LEFT, (const u32*)left, w.pose.p, w.pose0.p, w.poseLerp.p, w.vel.p, w.slabCode.p, w.slabFresh.p);
 	if (right && capacity) hipLaunchKernelGGL(k_slab_apply, grid, block, 0, w.stream, w.nb, capacity, w.slabStamp, (uint8_t)MI_SLAB_GHOST_RIGHT, (const u32*)right, w.pose.p, w.pose0.p, w.poseLerp.p, w.vel.p, w.slabCode.p, w.slabFresh.p);
 	hipLaunchKernelGGL(k_slab_retire, dim3((w.nb + 255) / 256), block, 0, w.stream, w.nb, w.slabStamp, left != nullptr, right != nullptr, w.aliveMask.p, w.slabCode.p, w.slabFresh.p, w.simMask.p);
+	w.activeDirty = true; // ghosts came and went
 }

@@ -32,23 +32,27 @@ MI_DEV bool aabbOverlap(float4 amin, float4 amax, float4 bmin, float4 bmax)
 	return true;
 }
 
-__global__ void __launch_bounds__(256) k_cell_assign(u32 nc, u32 hashMask, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+__global__ void __launch_bounds__(256) k_cell_assign(const u32* __restrict__ activeCols, u32 hashMask, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
 	u32* __restrict__ counters, u32* __restrict__ hashKey, u32* __restrict__ cellCount)
 {
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i == 0) { counters[CTR_FIRST_LARGE] = 0xFFFFFFFFu; counters[CTR_FIRST_INACTIVE] = 0xFFFFFFFFu; counters[CTR_PAIR_OVERFLOW] = 0u; } // "none" until k_gather_sorted / k_pairs say otherwise
-	if (i >= nc) return;
+	const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gid == 0) { counters[CTR_FIRST_LARGE] = 0xFFFFFFFFu; counters[CTR_FIRST_INACTIVE] = 0xFFFFFFFFu; counters[CTR_PAIR_OVERFLOW] = 0u; } // "none" until k_gather_sorted / k_pairs say otherwise
+	const u32 n = counters[CTR_ACTIVE_COLS];
 	float maxExtent = fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f);
 	float cell = maxExtent * 1.001f;
 	float invCell = 1.f / cell;
-	float4 mn = aabbMin[i], mx = aabbMax[i];
-	float e = fmaxf(fmaxf(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
-	u32 h;
-	if (mn.x > mx.x) { h = hashMask + 2; }    // empty AABB (body simulated elsewhere): sorts last, never visited
-	else if (e > maxExtent) { h = hashMask + 1; } // large: sorts behind every grid cell
-	else { h = hashCell(packCell(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell)), hashMask); }
-	hashKey[i] = h;
-	atomicAdd(&cellCount[h], 1u); // bucket sizes (cleared by k_build_colliders): the order by bucket is a counting sort, see k_cell_place
+	for (u32 a = gid; a < n; a += gridDim.x * blockDim.x)
+	{
+		const u32 i = activeCols[a];
+		float4 mn = aabbMin[i], mx = aabbMax[i];
+		float e = fmaxf(fmaxf(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+		u32 h;
+		if (mn.x > mx.x) { h = hashMask + 2; }    // empty AABB (body simulated elsewhere): sorts last, never visited
+		else if (e > maxExtent) { h = hashMask + 1; } // large: sorts behind every grid cell
+		else { h = hashCell(packCell(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell)), hashMask); }
+		hashKey[i] = h;
+		atomicAdd(&cellCount[h], 1u); // bucket sizes (cleared by k_build_colliders): the order by bucket is a counting sort, see k_cell_place
+	}
 }
 
 // Order of the colliders by cell bucket = what a stable sort by hash key would give (bucket after bucket, inside a bucket by
@@ -56,44 +60,48 @@ __global__ void __launch_bounds__(256) k_cell_assign(u32 nc, u32 hashMask, const
 // takes a slot of its bucket in arrival order (atomic cursor: cellBase[h] ends up at the bucket's END) -> k_cell_rank puts the few
 // colliders of a bucket in index order, so that the order, and with it the pair list, repeats from run to run.  (rocPRIM's merge
 // sort of the 100k keys was 12 launches, 70 us per step.)  The bucket of the colliders simulated elsewhere keeps arrival order: nobody visits it.
-__global__ void __launch_bounds__(256) k_cell_place(u32 nc, const u32* __restrict__ hashKey, u32* __restrict__ cellBase, u32* __restrict__ tmpIdx)
+__global__ void __launch_bounds__(256) k_cell_place(const u32* __restrict__ counters, const u32* __restrict__ activeCols, const u32* __restrict__ hashKey, u32* __restrict__ cellBase, u32* __restrict__ tmpIdx)
 {
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < nc) tmpIdx[atomicAdd(&cellBase[hashKey[i]], 1u)] = i;
+	const u32 n = counters[CTR_ACTIVE_COLS];
+	for (u32 a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) { const u32 i = activeCols[a]; tmpIdx[atomicAdd(&cellBase[hashKey[i]], 1u)] = i; }
 }
-__global__ void __launch_bounds__(256) k_cell_rank(u32 nc, u32 hashMask, const u32* __restrict__ hashKey, const u32* __restrict__ cellBase, const u32* __restrict__ cellCount, const u32* __restrict__ tmpIdx,
+__global__ void __launch_bounds__(256) k_cell_rank(const u32* __restrict__ counters, u32 hashMask, const u32* __restrict__ hashKey, const u32* __restrict__ cellBase, const u32* __restrict__ cellCount, const u32* __restrict__ tmpIdx,
 	u32* __restrict__ hashSorted, u32* __restrict__ idxSorted)
 {
-	u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= nc) return;
-	const u32 i = tmpIdx[t], h = hashKey[i], end = cellBase[h], start = end - cellCount[h];
-	u32 rank = t - start;
-	if (h != hashMask + 2u) { rank = 0; for (u32 u = start; u < end; ++u) rank += tmpIdx[u] < i ? 1u : 0u; }
-	hashSorted[start + rank] = h; idxSorted[start + rank] = i;
+	const u32 n = counters[CTR_ACTIVE_COLS];
+	for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+	{
+		const u32 i = tmpIdx[t], h = hashKey[i], end = cellBase[h], start = end - cellCount[h];
+		u32 rank = t - start;
+		if (h != hashMask + 2u) { rank = 0; for (u32 u = start; u < end; ++u) rank += tmpIdx[u] < i ? 1u : 0u; }
+		hashSorted[start + rank] = h; idxSorted[start + rank] = i;
+	}
 }
 
-__global__ void __launch_bounds__(256) k_gather_sorted(u32 nc, u32 hashMask, const u32* __restrict__ hashSorted, const u32* __restrict__ idxSorted,
+__global__ void __launch_bounds__(256) k_gather_sorted(u32 hashMask, const u32* __restrict__ hashSorted, const u32* __restrict__ idxSorted,
 	const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax, u32* __restrict__ counters,
 	u64* __restrict__ sCellKey, float4* __restrict__ sMin, float4* __restrict__ sMax, u32* __restrict__ cellStart, u32* __restrict__ cellEnd)
 {
-	u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= nc) return;
-	u32 idx = idxSorted[t];
-	u32 h = hashSorted[t];
+	const u32 nc = counters[CTR_ACTIVE_COLS];
 	float cell = fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f) * 1.001f;
 	float invCell = 1.f / cell;
-	float4 mn = aabbMin[idx], mx = aabbMax[idx];
-	mn.w = __uint_as_float(idx);
-	sMin[t] = mn; sMax[t] = mx;
-	sCellKey[t] = packCell(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell));
-	u32 hPrev = (t > 0) ? hashSorted[t - 1] : 0xFFFFFFFFu;
-	u32 hNext = (t + 1 < nc) ? hashSorted[t + 1] : 0xFFFFFFFFu;
-	if (h <= hashMask)
+	for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < nc; t += gridDim.x * blockDim.x)
 	{
-		if (hPrev != h) cellStart[h] = t;
-		if (hNext != h) cellEnd[h] = t + 1;
+		u32 idx = idxSorted[t];
+		u32 h = hashSorted[t];
+		float4 mn = aabbMin[idx], mx = aabbMax[idx];
+		mn.w = __uint_as_float(idx);
+		sMin[t] = mn; sMax[t] = mx;
+		sCellKey[t] = packCell(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell));
+		u32 hPrev = (t > 0) ? hashSorted[t - 1] : 0xFFFFFFFFu;
+		u32 hNext = (t + 1 < nc) ? hashSorted[t + 1] : 0xFFFFFFFFu;
+		if (h <= hashMask)
+		{
+			if (hPrev != h) cellStart[h] = t;
+			if (hNext != h) cellEnd[h] = t + 1;
+		}
+		else if (hPrev != h) { counters[h == hashMask + 1 ? CTR_FIRST_LARGE : CTR_FIRST_INACTIVE] = t; }
 	}
-	else if (hPrev != h) { counters[h == hashMask + 1 ? CTR_FIRST_LARGE : CTR_FIRST_INACTIVE] = t; }
 }
 
 // Overlapping partners of the collider at sorted position t.  Every pair is produced exactly once, as (A = this collider,
@@ -115,8 +123,8 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* 
 {
 	u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
 	u32 t = gid / PAIR_LANES, g = gid % PAIR_LANES;
-	bool valid = t < nc;
-	u32 nEnd = min(counters[CTR_FIRST_INACTIVE], nc);      // colliders behind this position have empty AABBs
+	bool valid = t < nc;                                   // nc = the launch's bound on the sorted positions (>= the active colliders, or the host repeats the broadphase)
+	u32 nEnd = min(counters[CTR_FIRST_INACTIVE], min(nc, counters[CTR_ACTIVE_COLS])); // colliders behind this position have empty AABBs
 	u32 firstLarge = min(counters[CTR_FIRST_LARGE], nEnd);
 	bool live = valid && t < nEnd;
 	if (MODE == MODE_WRITE) live = live && pairCount[t] > PAIR_SLAB; // everybody else is complete in its slab
@@ -203,13 +211,15 @@ __global__ void __launch_bounds__(256) k_pairs_pack(u32 nc, const u32* __restric
 // of this step's AABB centres (collision_broad.cpp:443-444: variance = s2 - s * s / numColliders; x over y, x over z, y over z on
 // ties), from the per-workgroup sums of k_build_colliders added up in a fixed order.  It goes to the word of step + 1's parity, so
 // that a step whose start is run twice (World::stepInternal after a recovered cluster sweep) leaves this step's own axis alone.
-__global__ void k_finish_pair_count(u32 nc, const u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, u32* __restrict__ counters, const double* __restrict__ sapPartial, u32 sapBlocks, u32 stepParity)
+__global__ void k_finish_pair_count(u32 launched, const u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, u32* __restrict__ counters, const double* __restrict__ sapPartial, u32 sapBlocks, u32 stepParity)
 {
 	double acc[7] = { 0., 0., 0., 0., 0., 0., 0. };
 	for (u32 b = threadIdx.x; b < sapBlocks; b += 64u) for (int k = 0; k < 7; ++k) acc[k] += sapPartial[(size_t)b * 7 + k];
 	for (int o = 32; o > 0; o >>= 1) for (int k = 0; k < 7; ++k) acc[k] += __shfl_xor(acc[k], o);
 	if (threadIdx.x == 0 && blockIdx.x == 0)
 	{
+		const u32 na = counters[CTR_ACTIVE_COLS], nc = min(na, launched);
+		counters[CTR_ACTIVE_OVERFLOW] = na > launched ? 1u : 0u; // more active colliders than the pair kernels and scans were launched for: the host repeats the broadphase
 		counters[CTR_NUM_PAIRS] = nc ? pairOffset[nc - 1] + pairCount[nc - 1] : 0;
 		counters[CTR_CELL_SIZE] = 0; // nobody reads the cell size after the pair traversal: ready for the next step's atomicMax
 		const double n = acc[6] > 0. ? acc[6] : 1.;
@@ -256,27 +266,32 @@ static u32 log2ceil(u32 v) { u32 b = 0; while ((1u << b) < v) ++b; return b; }
 
 void launch_broadphase_count(World& w)
 {
-	u32 nc = w.nc;
-	if (!nc) return;
-	dim3 grid((nc + 255) / 256), block(256);
+	if (!w.nc) return;
+	// kernels that walk the active colliders stride over whatever the device's count is; the pair kernels, their slabs and the scan
+	// are laid out for `bound` sorted positions (the last known count + 12 %): if the count has outgrown it the step repeats this
+	// function (World::stepInternal looks at CTR_ACTIVE_OVERFLOW)
+	const u32 bound = (u32)std::min<u64>(w.nc, (u64)w.estActiveCols + w.estActiveCols / 8u + 2048u);
+	w.pairBound = bound;
+	dim3 grid(std::max(1u, (bound + 255u) / 256u)), block(256);
 	u32 H = w.hashTableSize, mask = H - 1;
 	// cell size (max extent) and the cleared cell table come out of k_build_colliders
-	hipLaunchKernelGGL(k_cell_assign, grid, block, 0, w.stream, nc, mask, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.hashKey.p, w.cellCount.p);
+	hipLaunchKernelGGL(k_cell_assign, grid, block, 0, w.stream, w.actCols.p, mask, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.hashKey.p, w.cellCount.p);
 	prim_exclusive_scan_u32(w, w.cellCount.p, w.cellBase.p, H + 3);
-	hipLaunchKernelGGL(k_cell_place, grid, block, 0, w.stream, nc, w.hashKey.p, w.cellBase.p, w.sortIdx.p);
-	hipLaunchKernelGGL(k_cell_rank, grid, block, 0, w.stream, nc, mask, w.hashKey.p, w.cellBase.p, w.cellCount.p, w.sortIdx.p, w.hashKeySorted.p, w.sortIdxSorted.p);
-	hipLaunchKernelGGL(k_gather_sorted, grid, block, 0, w.stream, nc, mask, w.hashKeySorted.p, w.sortIdxSorted.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p,
+	hipLaunchKernelGGL(k_cell_place, grid, block, 0, w.stream, w.dCounters.p, w.actCols.p, w.hashKey.p, w.cellBase.p, w.sortIdx.p);
+	hipLaunchKernelGGL(k_cell_rank, grid, block, 0, w.stream, w.dCounters.p, mask, w.hashKey.p, w.cellBase.p, w.cellCount.p, w.sortIdx.p, w.hashKeySorted.p, w.sortIdxSorted.p);
+	hipLaunchKernelGGL(k_gather_sorted, grid, block, 0, w.stream, mask, w.hashKeySorted.p, w.sortIdxSorted.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p,
 		w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p);
-	w.pairSlab.ensure((size_t)nc * PAIR_SLAB, w.stream);
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_SLAB>), dim3((u32)(((size_t)nc * PAIR_LANES + 255) / 256)), block, 0, w.stream, nc, mask, w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p, w.dCounters.p,
+	w.pairSlab.ensure((size_t)bound * PAIR_SLAB, w.stream);
+	if (w.lastError) return;
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_SLAB>), dim3((u32)(((size_t)bound * PAIR_LANES + 255) / 256)), block, 0, w.stream, bound, mask, w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p, w.dCounters.p,
 		w.pairCount.p, w.pairOffset.p, w.pairSlab.p, 0u);
-	prim_exclusive_scan_u32(w, w.pairCount.p, w.pairOffset.p, nc);
-	hipLaunchKernelGGL(k_finish_pair_count, dim3(1), dim3(64), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.dCounters.p, w.sapPartial.p, (nc + 255) / 256, w.stats.numInternalSteps & 1u);
+	prim_exclusive_scan_u32(w, w.pairCount.p, w.pairOffset.p, bound);
+	hipLaunchKernelGGL(k_finish_pair_count, dim3(1), dim3(64), 0, w.stream, bound, w.pairCount.p, w.pairOffset.p, w.dCounters.p, w.sapPartial.p, w.sapBlocks, w.stats.numInternalSteps & 1u);
 }
 
 void launch_broadphase_write(World& w, u32 numPairs, bool slabOverflow)
 {
-	u32 nc = w.nc;
+	const u32 nc = w.pairBound;
 	if (!nc || !numPairs) return;
 	hipLaunchKernelGGL(k_pairs_pack, dim3((u32)(((size_t)nc * PAIR_SLAB + 255) / 256)), dim3(256), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.pairSlab.p, w.pairs.p, (u32)w.pairCap);
 	if (slabOverflow) // some colliders have more than PAIR_SLAB partners: those (only) repeat their traversal, writing in place

@@ -94,6 +94,9 @@ enum
 	CTR_CL_PHASE_COUNT = 431,// 5 words: statistics: manifolds per phase
 	CTR_CL_BBOX = 436,      // 6 words: min xyz, max xyz of the simulated bodies' centres of gravity (order-preserving integer encoding)
 	CTR_CL_LEFT = 372,      // 5 words: cluster build: manifolds left over by the curve phases (cursor of the list the component phase works on); statistics of the component phase: tasks, total weight, manifolds whose ends disagree, weight of the largest component sent to the rest task
+	CTR_ACTIVE_BODIES = 377, // simulated bodies / their colliders + the static ones (lengths of the active lists, k_active_scan); more of the latter than the broadphase was launched for
+	CTR_ACTIVE_COLS = 378,
+	CTR_ACTIVE_OVERFLOW = 379,
 	CTR_CL_SCRATCH = 371,   // cluster sweep: append cursor of the global row scratch (contacts that fit neither registers nor LDS), reset before every launch
 	CTR_VALIDATE = 448,     // 2 words: non-finite values found by the debug guard (MI_PHYSICS_VALIDATE=1), first offender (stage << 28 | index)
 	CTR_CL_REMAIN = 442,    // 6 words: manifolds still unassigned when partition phase p starts ([0] unused: all active ones)
@@ -169,6 +172,8 @@ struct World
 	DevBuf<u32> cellCount, cellBase;      // colliders per cell bucket (+ 'large', 'simulated elsewhere'), first / end position of every bucket in the sorted order
 	DevBuf<u32> hashKey, hashKeySorted, sortIdx, sortIdxSorted, cellStart, cellEnd, largeFlag, largeScan, largeList, pairCount, pairOffset;
 	DevBuf<u64> sCellKey; DevBuf<float4> sMin, sMax;
+	// active lists (k_bodies.hip): the simulated bodies, their colliders + the static ones, ascending; rebuilt when the simulate mask may have changed
+	DevBuf<u32> actBodies, actCols, actBlockCount, actBlockBase, colBody; bool activeDirty = true; u32 estActiveBodies = 0, estActiveCols = 0, pairBound = 0, sapBlocks = 0;
 	DevBuf<double> sapPartial;            // per workgroup of k_build_colliders: sum of the AABB centres (3), of their squares (3), colliders counted (1)
 	DevBuf<uint2> pairs, pairSlab;
 	u32 hashTableSize = 0;
@@ -264,6 +269,9 @@ struct World
 };
 
 // ---- launchers (one per stage; each defined next to its kernels) --------------------------------------------------
+void launch_active_lists(World& w);                        // (re)builds the lists of simulated bodies / colliders if the simulate mask may have changed
+void launch_restore_velocities(World& w);                  // velocities of the simulated bodies <- velBackup
+u32 active_grid(u32 estimate, u32 total);
 void launch_build_colliders(World& w);
 void launch_broadphase_count(World& w);                    // grid build + pair count + scan; leaves numPairs in dCounters
 void launch_broadphase_write(World& w, u32 numPairs, bool slabOverflow);       // slabOverflow: some collider has more partners than its slab holds (CTR_PAIR_OVERFLOW)

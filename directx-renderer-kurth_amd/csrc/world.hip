@@ -374,11 +374,16 @@ void World::upload()
 		MI_CHECK(hipMemcpyAsync(force.p, hf.data(), sizeof(float4) * hf.size(), hipMemcpyHostToDevice, stream));
 	}
 	MI_CHECK(hipMemcpyAsync(vel.p, hv.data(), sizeof(float4) * hv.size(), hipMemcpyHostToDevice, stream));
+	std::vector<u32> hcb(newNc);
+	for (u32 i = 0; i < newNc; ++i) hcb[i] = (colliders[i].body == MI_STATIC_BODY) ? newNb : colliders[i].body;
+	colBody.ensure(ncap, stream);
 	if (nc)
 	{
 		MI_CHECK(hipMemcpyAsync(colLocal.p, hc.data(), sizeof(ColliderRec) * hc.size(), hipMemcpyHostToDevice, stream));
 		MI_CHECK(hipMemcpyAsync(colStaticPose.p, hsp.data(), sizeof(float4) * hsp.size(), hipMemcpyHostToDevice, stream));
+		MI_CHECK(hipMemcpyAsync(colBody.p, hcb.data(), sizeof(u32) * hcb.size(), hipMemcpyHostToDevice, stream));
 	}
+	activeDirty = true; estActiveBodies = nb; estActiveCols = nc; // (the lists are rebuilt at the next step; until the host has seen their lengths the launches are sized for everything)
 	MI_CHECK(hipStreamSynchronize(stream));
 	topologyDirty = false; stateOnDevice = true; bufferVersion++;
 	jointsDirty = true; // the static dummy index (= nb) moved
@@ -663,7 +668,7 @@ void World::recoverFlow()
 	const size_t nb1 = (size_t)nb + 1;
 	MI_CHECK(hipMemsetAsync(dCounters.p + CTR_FLOW_STATUS, 0, sizeof(u32), stream));
 	MI_CHECK(hipMemsetAsync(dCounters.p + CTR_NUM_ACTIVE, 0, 2 * sizeof(u32), stream)); // active-list cursor + contact count: the list is rebuilt
-	MI_CHECK(hipMemcpyAsync(vel.p, velBackup.p, sizeof(float4) * 2 * nb1, hipMemcpyDeviceToDevice, stream));
+	launch_restore_velocities(*this); // (the simulated bodies': the backup holds nothing of the others)
 	MI_CHECK(hipMemsetAsync(bodyMask.p, 0, sizeof(u64) * nb1, stream));
 	MI_CHECK(hipMemsetAsync(claim.p, 0xFF, sizeof(u64) * 2 * nb1, stream));
 	forceFullColoring = true;
@@ -799,6 +804,13 @@ int World::stepInternal(float dt, u32 iters)
 		early = false;
 	}
 	flowPending = false;
+	estActiveBodies = hCounters[CTR_ACTIVE_BODIES]; estActiveCols = hCounters[CTR_ACTIVE_COLS]; // lengths of the active lists: size the next launches
+	if (hCounters[CTR_ACTIVE_OVERFLOW])                    // more active colliders than the pair kernels were laid out for (the lists grew by more than 12 % in one step)
+	{
+		launch_broadphase_count(*this);                    // (now with the right bound)
+		readCounters(*this);
+		early = false;
+	}
 	if (hCounters[CTR_VALIDATE])                           // the debug guard found NaN / Inf in the previous step (or in this step's colliders)
 	{
 		static const char* stageName[4] = { "world-space colliders / boxes", "contacts", "body update records (centre of gravity, inverse inertia, velocities)", "poses / velocities after the step" };
@@ -1831,6 +1843,7 @@ int mi_delete_body(mi_world* world, uint32_t body)
 		float4 still[2] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f) }; // gone: no velocity, no mass
 		MI_CHECK(hipMemcpyAsync(W->vel.p + 2 * body, still, sizeof(still), hipMemcpyHostToDevice, W->stream));
 		MI_CHECK(hipMemcpyAsync(W->simMask.p + body, &zero, 1, hipMemcpyHostToDevice, W->stream));
+		W->activeDirty = true;
 		MI_CHECK(hipMemcpyAsync(W->aliveMask.p + body, &zero, 1, hipMemcpyHostToDevice, W->stream));
 		MI_CHECK(hipStreamSynchronize(W->stream));
 	}
