@@ -1006,7 +1006,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 		for (u32 p = 0; p < CL_MAX_PHASES; ++p)
 		{
 			u32 tasksInPhase = A.counters[CTR_CL_NUM_TASKS + p];
-			if (tasksInPhase > CL_TASKS_PER_PHASE * G) bad = true;
+			if (tasksInPhase > CL_TASKS_PER_PHASE * G) { bad = true; atomicOr(status, 128u); }
 			// task t of phase p runs on workgroup (clPhaseOffset + t) % G; a phase with more tasks than workgroups wraps around (its tasks
 			// share no body, so a workgroup may run two of them one after the other)
 			off = clPhaseOffset(A.counters, p);
@@ -1017,11 +1017,11 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 				const ClTask* T = A.tasks + key;
 				const u32 tj = (A.jointClassStart && p == 0u) ? A.jointClassStart[(size_t)key * (CL_MAX_JOINT_CLASSES + 2u) + CL_MAX_JOINT_CLASSES] : 0u; // joints of the task
 				if (!T->count && !tj) continue;
-				if (nT == CL_MAX_LOCAL_TASKS) { bad = true; break; }
+				if (nT == CL_MAX_LOCAL_TASKS) { bad = true; atomicOr(status, 256u); break; }
 				ClLocal& L = sTask[nT];
 				L.first = T->first; L.count = T->count; L.numBodies = T->numBodies; L.numShared = T->numShared; L.numColors = T->numColors; L.serialStart = T->serialStart; L.numContacts = T->numRows;
 				L.phase = p; L.key = key; L.sharedBase = T->sharedBase; L.numJoints = tj;
-				if (tj > CLS_LANES || (tj && nT)) bad = true; // one lane per joint; joints run with the workgroup's first task only
+				if (tj > CLS_LANES || (tj && nT)) { bad = true; atomicOr(status, 2048u); } // one lane per joint; joints run with the workgroup's first task only
 				for (u32 c = 0; c <= CL_SERIAL_COLOR + 1u; ++c) L.colorStart[c] = T->colorStart[c];
 				L.colorStart[CL_SERIAL_COLOR + 2u] = L.colorStart[CL_SERIAL_COLOR + 1u]; L.colorStart[CL_SERIAL_COLOR + 3u] = L.colorStart[CL_SERIAL_COLOR + 1u]; // (the colour loop reads two entries ahead)
 				L.bodyOff = used; used += 2u * L.numBodies;
@@ -1031,7 +1031,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 				++nT;
 			}
 		}
-		if (used + CLQ_ZERO_FLOAT4S > A.ldsFloat4s) bad = true; // the bodies alone exceed LDS: cannot run this launch
+		if (used + CLQ_ZERO_FLOAT4S > A.ldsFloat4s) { bad = true; atomicOr(status, 512u); } // the bodies alone exceed LDS: cannot run this launch
 		// rows beyond the register sets: whatever LDS is left, in task order
 		for (u32 k = 0; k < nT && !bad; ++k)
 		{
@@ -1041,7 +1041,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 			u32 fit = left / CLQ_ROW_FLOAT4S;
 			u32 cap = want < fit ? want : fit;              // what does not fit goes to the global scratch (L2-resident, every step of such a task waits for it: the cluster build sizes the later phases' tasks so that this is rare)
 			L.rowOff = used; L.rowCap = cap; used += CLQ_ROW_FLOAT4S * cap; L.scratchBase = 0;
-			if (want > cap) { L.scratchBase = atomicAdd(&A.counters[CTR_CL_SCRATCH], want - cap); if (L.scratchBase + (want - cap) > A.scratchContacts) { bad = true; break; } }
+			if (want > cap) { L.scratchBase = atomicAdd(&A.counters[CTR_CL_SCRATCH], want - cap); if (L.scratchBase + (want - cap) > A.scratchContacts) { bad = true; atomicOr(status, 1024u); break; } }
 		}
 		if (bad) atomicOr(status, 64u);
 		sNumTasks = nT; sAbort = (bad || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ? 1u : 0u;

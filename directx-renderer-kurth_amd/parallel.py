@@ -160,14 +160,42 @@ class SlabWorld:
         self.right = rank + 1 if rank < world_size - 1 else None
         self.margin, self.cuts, self.recut_interval, self.steps, self.recuts = margin, cuts, int(recut_interval), 0, 0
         self.world.slab_configure(rank, world_size, self.axis, lo, hi, margin)
-        self.capacity = int(capacity or max(4096, n // max(2, world_size)))
-        nbytes = self.world.slab_message_bytes(self.capacity)
+        # Message capacity (records per neighbour and direction; the whole fixed-size message travels every step): twice the band
+        # population, measured — at the start from the scene (bodies within `margin` of any cut, the fullest band of ALL ranks, so that
+        # every rank arrives at the same size without talking), then every `resize_interval` steps from the messages' own headers
+        # (one all-reduce, off the per-step path).  A message that overflowed is an error, never silent.
+        self.fixed_capacity = capacity is not None
+        if capacity is None:
+            xs = x0[:, self.axis]
+            band = max([int(((xs >= c - margin) & (xs < c + margin)).sum()) for c in cuts] + [0])
+            capacity = max(1024, 2 * band)
+        self.capacity, self.resize_interval = int(capacity), 32
         self.stream = torch.cuda.ExternalStream(self.world.device_pointers()[2], device=self.dev)  # the world's stream: torch's comm work is enqueued on it
+        self._allocate_messages()
+        self.bytes_sent = 0
+        self.host_syncs = 0      # synchronisations the exchange itself adds (0 on the RCCL path between capacity checks)
+
+    def _allocate_messages(self):
+        nbytes = self.world.slab_message_bytes(self.capacity)
         with torch.cuda.stream(self.stream):
             self.out = {nb: torch.zeros(nbytes, dtype=torch.uint8, device=self.dev) for nb in (self.left, self.right) if nb is not None}
             self.inc = {nb: torch.zeros(nbytes, dtype=torch.uint8, device=self.dev) for nb in (self.left, self.right) if nb is not None}
-        self.bytes_sent = 0
-        self.host_syncs = 0      # synchronisations the exchange itself adds (0 on the RCCL path)
+
+    def check_capacity(self):
+        """Collective, every `resize_interval` steps: the fullest message of any rank decides the next capacity (2 x, same on all ranks);
+        a message that did not hold its band raises."""
+        self.world.synchronize()
+        head = [t[:8].cpu().view(torch.int32) for t in self.out.values()]
+        self.host_syncs += 1
+        mine = torch.tensor([max([int(h[0]) for h in head] + [0]), sum(int(h[1]) for h in head)], dtype=torch.int64, device="cpu" if self.comm_on_cpu else self.dev)
+        dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+        fullest, dropped = int(mine[0]), int(mine[1])
+        if dropped:
+            raise RuntimeError("slab halo: %d bodies did not fit a message of %d records (capacity is adapted every %d steps: the band filled faster than 2x)" % (dropped, self.capacity, self.resize_interval))
+        want = max(1024, 2 * fullest)
+        if not self.fixed_capacity and (want > self.capacity or want < self.capacity // 2):
+            self.capacity = want
+            self._allocate_messages()
 
     def _ptr(self, table, nb):
         return table[nb].data_ptr() if nb is not None else 0
@@ -210,6 +238,8 @@ class SlabWorld:
     def step_internal(self, dt, iterations=30):
         if self.world_size > 1 and self.recut_interval and self.steps and self.steps % self.recut_interval == 0:
             self.recut()
+        if self.world_size > 1 and self.steps and self.steps % self.resize_interval == 0:
+            self.check_capacity()
         self.exchange()
         self.world.step_internal(dt, iterations)
         self.steps += 1

@@ -372,6 +372,11 @@ class OracleWorld:
     def sorting_axis(self):
         return self.lib.orc_sorting_axis_used(self.w), self.lib.orc_sorting_axis_next(self.w)
 
+    def set_sim_mask(self, simulate):
+        """Per body: non-zero = simulated in this world; the others' colliders take no part and their state is frozen (a spatial slab)."""
+        m = np.ascontiguousarray(simulate, np.uint8)
+        self.lib.orc_set_sim_mask(self.w, m.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint32(len(m)))
+
     def set_sorting_axis(self, axis):
         """sap_context::sortingAxis of the next broadphase (a world taking over another world's state mid-run)."""
         self.lib.orc_set_sorting_axis(self.w, C.c_uint32(int(axis)))

@@ -95,6 +95,7 @@ struct world
 	// sap_context (collision_broad.cpp:20-24)
 	std::vector<sap_endpoint> endpoints;
 	u32 sortingAxis = 0;
+	std::vector<u8> simOff; // per body: 1 = not simulated in this world (a spatial slab of a multi-GPU run simulates what it owns plus ghosts): its colliders take no part, its state is frozen
 	float lastVariance[3] = { 0.f, 0.f, 0.f }; // of the last broadphase's AABB centres (the next axis is their argmax): tests look at near ties
 
 	// Per-step arrays kept for inspection by tests.
@@ -306,7 +307,7 @@ static void getWorldSpaceColliders(world& w)
 		if (c.parent != STATIC_BODY) { col.objectIndex = c.parent; col.objectType = physics_object_type_rigid_body; }
 		else if (c.zoneType != physics_object_type_static_collider) { col.objectIndex = c.zoneIndex; col.objectType = c.zoneType; } // physics.cpp:657-666
 		else { col.objectIndex = dummyRigidBodyIndex; col.objectType = physics_object_type_static_collider; }
-		if (c.parent != STATIC_BODY && w.bodies[c.parent].removed)
+		if (c.parent != STATIC_BODY && (w.bodies[c.parent].removed || (c.parent < w.simOff.size() && w.simOff[c.parent])))
 		{
 			// deleted entity: the reference takes the collider out of the sweep (collision_broad.cpp:42-75); keeping collider indices
 			// stable, it is parked where it can overlap nothing instead
@@ -384,6 +385,7 @@ static void broadphase(world& w)
 	u32 numEndpoints = numColliders * 2;
 
 	vec3 s(0.f), s2(0.f);
+	u32 numCounted = 0;
 	u32 sortingAxis = w.sortingAxis;
 	w.usedSortingAxis = sortingAxis;
 	{
@@ -396,9 +398,12 @@ static void broadphase(world& w)
 		}
 		for (u32 i = 0; i < numColliders; ++i)
 		{
+			const u32 parent = w.colliders[i].parent;
+			if (parent != STATIC_BODY && (w.bodies[parent].removed || (parent < w.simOff.size() && w.simOff[parent]))) { continue; } // (parked: not a collider of this world's sweep; the reference removes a deleted entity's endpoints, collision_broad.cpp:42-75)
 			vec3 center = w.worldSpaceAABBs[i].getCenter();
 			s += center;
 			s2 += center * center;
+			++numCounted;
 		}
 	}
 	for (u32 i = 1; i < numEndpoints; ++i) // insertion sort (:387-398), stable, strict >
@@ -437,7 +442,7 @@ static void broadphase(world& w)
 			activeBBs[pos] = activeBBs[numActive];
 		}
 	}
-	vec3 variance = s2 - s * s / (float)numColliders;
+	vec3 variance = s2 - s * s / (float)(numCounted ? numCounted : 1u);
 	w.lastVariance[0] = variance.x; w.lastVariance[1] = variance.y; w.lastVariance[2] = variance.z;
 	w.sortingAxis = (variance.x > variance.y) ? ((variance.x > variance.z) ? 0 : 2) : ((variance.y > variance.z) ? 1 : 2);
 }
@@ -812,6 +817,7 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 	w.rbGlobal.resize(numRigidBodies + 1);
 	for (u32 i = 0; i < numRigidBodies; ++i)
 	{
+		if (i < w.simOff.size() && w.simOff[i]) { memset(&w.rbGlobal[i], 0, sizeof(rigid_body_global_state)); continue; } // simulated elsewhere: frozen here
 		if (anyGlobalForce) { w.bodies[i].forceAccumulator += globalForce; }        // :1273
 		applyGravityAndIntegrateForces(w.bodies[i], w.rbGlobal[i], w.bodies[i].transform1, dt);
 	}
@@ -910,7 +916,7 @@ static void physicsStepInternal(world& w, u32 iterations, u32 mode, float dt)
 	}
 
 	stageEnd(3);
-	for (u32 i = 0; i < numRigidBodies; ++i) { integrateVelocity(w.bodies[i], w.rbGlobal[i], w.bodies[i].transform1, dt); }
+	for (u32 i = 0; i < numRigidBodies; ++i) { if (i < w.simOff.size() && w.simOff[i]) continue; integrateVelocity(w.bodies[i], w.rbGlobal[i], w.bodies[i].transform1, dt); }
 	stageEnd(4);
 
 	for (cloth& c : w.cloths) // physics.cpp:1354-1358
@@ -1488,6 +1494,7 @@ u32 orc_num_contacts(world* w) { return (u32)w->contacts.size(); }
 u32 orc_num_collisions(world* w) { return (u32)w->collidingPairs.size(); }
 u32 orc_sorting_axis_used(world* w) { return w->usedSortingAxis; }
 u32 orc_sorting_axis_next(world* w) { return w->sortingAxis; }
+void orc_set_sim_mask(world* w, const u8* simulate, u32 n) { w->simOff.assign(w->bodies.size(), 0); for (u32 i = 0; i < n && i < w->simOff.size(); ++i) w->simOff[i] = simulate[i] ? 0 : 1; }
 void orc_set_sorting_axis(world* w, u32 axis) { if (axis < 3u) w->sortingAxis = axis; } // a world that takes over another's state mid-run takes its sap_context::sortingAxis too
 void orc_sorting_variance(world* w, float* out3) { for (int k = 0; k < 3; ++k) out3[k] = w->lastVariance[k]; }
 
