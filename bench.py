@@ -11,7 +11,7 @@ exchange per step (directx-renderer-kurth_amd/parallel.py); "scaling": "strong".
 One JSON line on rank 0.  `roofline` prices the dominant kernel (contact solve: k_cl_solve, the LDS cluster sweep, all 30 iterations
 in one launch) with the fixed algorithmic figure of BASELINE.md (240 B per contact per iteration) against HIP-event time measured on
 the world's stream inside the timed region; `stage_roofline` does the same per stage with SURVEY section 8(d)'s per-unit bytes;
-`cpu_baseline` times the oracle's 8-lane "AVX2 restatement" of the reference solver (single thread) on a bounded sample that starts
+`cpu_baseline` times the oracle's 8-lane "AVX2 restatement" of the reference (8-wide sweep, greedy batch scheduler, 8-wide solver; single thread) on a bounded sample that starts
 from the state at the BEGINNING of the timed window.  After the timed region the state is checked (finite, nothing below the ground,
 no solver recovery): a number measured on a broken simulation is not printed.
 """
@@ -34,6 +34,7 @@ def cpu_baseline(scene, transforms, velocities, first_step, seconds=12.0, max_st
     """Oracle 8-lane path (liboracle_avx2.so, -O3 -mavx2 -mfma), one thread, started from the device's state at the first timed step."""
     from oracle import oracle as orc
     w = scene.instantiate(orc.OracleWorld(avx2=True, solver=orc.SOLVER_WIDE8))
+    w.set_wide_broadphase(True)     # the reference's 8-wide sweep (collision_broad.cpp:168-295), like its 8-wide solver
     w.write_state(transforms, velocities, presort=True)
     w.step_internal(scene.dt)  # untimed: first broadphase after the state injection (an insertion sort from scratch)
     w.stage_seconds(reset=True)
@@ -48,7 +49,7 @@ def cpu_baseline(scene, transforms, velocities, first_step, seconds=12.0, max_st
     return {"value": n / dt, "unit": "steps/s", "cores": 1, "kind": "port",
             "stage_ms": dict(zip(("msCollidersBroad", "msNarrow", "msSolverSetup", "msSolve", "msIntegrate"), [round(float(x) / n * 1e3, 2) for x in stages])),
             "sample": "%d steps from the state at timed step %d (%d contacts at the end), oracle 8-lane AVX2 restatement of the reference solver incl. its greedy batch scheduler, "
-                      "scalar sort-and-sweep broadphase, 1 thread; the reference binary itself cannot be built (MSVC/Windows) and its u16 indices cannot hold this config" % (n, first_step, contacts)}
+                      "8-wide sort-and-sweep broadphase (the reference's determineOverlapsSIMD), 1 thread; the reference binary itself cannot be built (MSVC/Windows) and its u16 indices cannot hold this config" % (n, first_step, contacts)}
 
 
 def pmc_traffic(contacts):

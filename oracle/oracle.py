@@ -372,6 +372,10 @@ class OracleWorld:
     def sorting_axis(self):
         return self.lib.orc_sorting_axis_used(self.w), self.lib.orc_sorting_axis_next(self.w)
 
+    def set_wide_broadphase(self, on=True):
+        """physics_settings::simdBroadPhase: the 8-wide sweep (collision_broad.cpp:168-295) instead of the scalar one; same pair list."""
+        self.lib.orc_set_wide_broadphase(self.w, int(on))
+
     def set_sim_mask(self, simulate):
         """Per body: non-zero = simulated in this world; the others' colliders take no part and their state is frozen (a spatial slab)."""
         m = np.ascontiguousarray(simulate, np.uint8)

@@ -95,6 +95,7 @@ struct world
 	// sap_context (collision_broad.cpp:20-24)
 	std::vector<sap_endpoint> endpoints;
 	u32 sortingAxis = 0;
+	bool wideBroadphase = false; // the sweep of determineOverlapsSIMD (8 active boxes per compare) instead of determineOverlapsScalar: same pair list, what the reference's AVX2 build runs
 	std::vector<u8> simOff; // per body: 1 = not simulated in this world (a spatial slab of a multi-GPU run simulates what it owns plus ghosts): its colliders take no part, its state is frozen
 	float lastVariance[3] = { 0.f, 0.f, 0.f }; // of the last broadphase's AABB centres (the next axis is their argmax): tests look at near ties
 
@@ -414,6 +415,50 @@ static void broadphase(world& w)
 		endpoints[j + 1] = key;
 	}
 
+	if (w.wideBroadphase) // determineOverlapsSIMD (:168-295): the active boxes in SoA blocks of 8, one start endpoint against 8 of them at a time (physics_settings::simdBroadPhase)
+	{
+		const u32 W = 8;
+		struct soa_bounding_box { float minX[8], minY[8], minZ[8], maxX[8], maxY[8], maxZ[8]; };
+		std::vector<u32> activeList((numColliders + W - 1) / W * W), positionInActiveList(numColliders);
+		std::vector<soa_bounding_box> activeBBs((numColliders + W - 1) / W);
+		u32 numActive = 0;
+		for (u32 i = 0; i < numEndpoints; ++i)
+		{
+			sap_endpoint ep = endpoints[i];
+			if (ep.start)
+			{
+				const bounding_box& a = w.worldSpaceAABBs[ep.collider];
+				const u32 count = (numActive + W - 1) / W;
+				for (u32 active = 0; active < count; ++active)
+				{
+					const soa_bounding_box& b = activeBBs[active];
+					const u32 numValidLanes = std::min(numActive - active * W, W);
+					u32 mask = 0;
+					for (u32 k = 0; k < W; ++k) // aabbVsAABB on 8 lanes (bounding_volumes_simd.h:59-66): inclusive compares, combined with &
+						mask |= (u32)((a.maxCorner.x >= b.minX[k]) & (a.minCorner.x <= b.maxX[k]) & (a.maxCorner.y >= b.minY[k]) & (a.minCorner.y <= b.maxY[k]) & (a.maxCorner.z >= b.minZ[k]) & (a.minCorner.z <= b.maxZ[k])) << k;
+					mask &= (1u << numValidLanes) - 1u;
+					for (u32 k = 0; k < W; ++k) if (mask & (1u << k)) w.broadphasePairs.push_back({ ep.collider, activeList[active * W + k] });
+				}
+				positionInActiveList[ep.collider] = numActive;
+				soa_bounding_box& out = activeBBs[numActive / W]; const u32 slot = numActive % W;
+				out.minX[slot] = a.minCorner.x; out.minY[slot] = a.minCorner.y; out.minZ[slot] = a.minCorner.z; out.maxX[slot] = a.maxCorner.x; out.maxY[slot] = a.maxCorner.y; out.maxZ[slot] = a.maxCorner.z;
+				activeList[numActive++] = ep.collider;
+			}
+			else
+			{
+				const u32 pos = positionInActiveList[ep.collider];
+				--numActive;
+				const u32 last = activeList[numActive];
+				positionInActiveList[last] = pos;
+				activeList[pos] = activeList[numActive];
+				soa_bounding_box& out = activeBBs[pos / W]; const u32 slot = pos % W;
+				const soa_bounding_box& from = activeBBs[numActive / W]; const u32 fromSlot = numActive % W;
+				out.minX[slot] = from.minX[fromSlot]; out.minY[slot] = from.minY[fromSlot]; out.minZ[slot] = from.minZ[fromSlot]; out.maxX[slot] = from.maxX[fromSlot]; out.maxY[slot] = from.maxY[fromSlot]; out.maxZ[slot] = from.maxZ[fromSlot];
+			}
+		}
+	}
+	else
+	{
 	// determineOverlapsScalar (:87-166)
 	std::vector<u32> activeList(numColliders), positionInActiveList(numColliders);
 	std::vector<bounding_box> activeBBs(numColliders);
@@ -441,6 +486,7 @@ static void broadphase(world& w)
 			activeList[pos] = activeList[numActive];
 			activeBBs[pos] = activeBBs[numActive];
 		}
+	}
 	}
 	vec3 variance = s2 - s * s / (float)(numCounted ? numCounted : 1u);
 	w.lastVariance[0] = variance.x; w.lastVariance[1] = variance.y; w.lastVariance[2] = variance.z;
@@ -1494,6 +1540,7 @@ u32 orc_num_contacts(world* w) { return (u32)w->contacts.size(); }
 u32 orc_num_collisions(world* w) { return (u32)w->collidingPairs.size(); }
 u32 orc_sorting_axis_used(world* w) { return w->usedSortingAxis; }
 u32 orc_sorting_axis_next(world* w) { return w->sortingAxis; }
+void orc_set_wide_broadphase(world* w, int on) { w->wideBroadphase = on != 0; }
 void orc_set_sim_mask(world* w, const u8* simulate, u32 n) { w->simOff.assign(w->bodies.size(), 0); for (u32 i = 0; i < n && i < w->simOff.size(); ++i) w->simOff[i] = simulate[i] ? 0 : 1; }
 void orc_set_sorting_axis(world* w, u32 axis) { if (axis < 3u) w->sortingAxis = axis; } // a world that takes over another's state mid-run takes its sap_context::sortingAxis too
 void orc_sorting_variance(world* w, float* out3) { for (int k = 0; k < 3; ++k) out3[k] = w->lastVariance[k]; }

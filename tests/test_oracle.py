@@ -454,3 +454,22 @@ def test_oracle_under_sanitizers():
         pytest.skip("sanitizer runtime not installed")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count("mode ") == 3
+
+
+@pytest.mark.parametrize("name,steps", [("c1", 60), ("c3_small", 40), ("shapes", 30)])
+def test_wide_sweep_reports_the_scalar_sweeps_pairs(oracle, name, steps):
+    """determineOverlapsSIMD (collision_broad.cpp:168-295: the active boxes in SoA blocks of eight, one start endpoint against eight of
+    them per compare) against determineOverlapsScalar (:87-166): the same pairs in the same order, step after step (the reference
+    switches between them with physics_settings::simdBroadPhase; the cpu_baseline of bench.py times the wide one)."""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name(name)
+    a = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_SCALAR))
+    b = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_SCALAR)); b.set_wide_broadphase(True)
+    most = 0
+    for i in range(steps):
+        a.step_internal(scene.dt); b.step_internal(scene.dt)
+        pa, pb = a.pairs(), b.pairs()
+        assert np.array_equal(pa, pb), "step %d: the wide sweep's pair list differs" % i
+        most = max(most, len(pa))
+    assert most > 0 and np.array_equal(a.transforms(1), b.transforms(1))
+
