@@ -156,6 +156,11 @@ def main():
         cluster = st["clusterTasks"][0] > 0 if "clusterTasks" in st else False  # cluster sweep: all 30 iterations in ONE launch of k_cl_solve
         launches_per_step = 1.0 if cluster else max(1.0, mean["numColors"]) * 30.0
         bytes_per_step = ALGORITHMIC_BYTES_PER_CONTACT_ITERATION * contacts * 30.0
+        # joints solved by the same launch (config 4): SURVEY section 8(d)'s per joint-iteration figures (row + ids + 2 x (64 B body read + 24 B write))
+        joint_bytes = {"hinge": 196 + 8 + 2 * (64 + 24), "cone_twist": 245 + 8 + 2 * (64 + 24)}
+        joint_counts = {k: sum(1 for j in scene.joints if (j[0][:-6] if j[0].endswith("_local") else j[0]) == k) for k in joint_bytes}
+        joint_bytes_per_step = 30.0 * sum(joint_bytes[k] * n for k, n in joint_counts.items())
+        bytes_per_step += joint_bytes_per_step
         solve_s = mean["msSolve"] * 1e-3
         achieved = bytes_per_step / solve_s / 1e9 if solve_s > 0 else 0.0
         traffic, traffic_src = pmc_traffic(contacts) if cluster else (None, None)
@@ -182,7 +187,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_cl_solve (contact PGS sweep, 30 iterations in one launch, LDS clusters)" if cluster else "k_solve_color (contact PGS sweep, one launch per colour and iteration)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_per_step / launches_per_step, "avg_launch_us": solve_s / launches_per_step * 1e6,
-                         "launches_per_step": launches_per_step},
+                         "launches_per_step": launches_per_step,
+                         "joint_bytes_per_launch": joint_bytes_per_step / launches_per_step, "joints_priced": joint_counts},
             "stage_roofline": {k: {"algorithmic_bytes": round(b), "GBps": round(b / (mean[k] * 1e-3) / 1e9, 1) if mean[k] > 0 else 0.0, "frac": round(b / (mean[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if mean[k] > 0 else 0.0}
                                for k, b in stage_bytes.items()},
         }

@@ -393,26 +393,29 @@ void World::upload()
 void World::uploadJoints()
 {
 	if (!jointsDirty) return;
+	// Colours ACROSS the types: a joint's colour ("level") is the lowest one above every colour already given to a joint of either of its
+	// bodies, the joints taken in the reference's solve order (type after type, constraints.cpp:3748-3772; inside a type in storage
+	// order).  Joints of one level share no body, and along every body the levels rise in that solve order, so "level by level" is
+	// the reference's sequence with commuting solves swapped — and joints of DIFFERENT types that share no body get the same level
+	// (a ragdoll: 5 levels instead of 1 hinge + 5 cone-twist colours = 6 dependent steps per iteration).
+	std::vector<u32> nextLevel(bodies.size() + 1, 0u);
+	u32 numLevels = 0;
 	for (u32 t = 0; t < MI_JOINT_TYPES; ++t)
 	{
 		JointSet& js = joints[t];
 		u32 n = js.count(), podSize = MI_JOINT_POD_SIZE[t];
 		std::vector<u32> color(n, 0xFFFFFFFFu);
-		std::map<u32, std::vector<bool>> used;
 		u32 numColors = 0;
 		for (u32 i = 0; i < n; ++i)
 		{
 			if (!js.alive[i]) continue;
-			std::vector<bool>& ua = used[js.a[i]]; std::vector<bool>& ub = used[js.b[i]];
-			u32 c = 0;
-			for (;; ++c) { bool fa = c < ua.size() && ua[c], fb = c < ub.size() && ub[c]; if (!fa && !fb) break; }
-			if (ua.size() <= c) ua.resize(c + 1, false);
-			ua[c] = true;
-			std::vector<bool>& ub2 = used[js.b[i]];
-			if (ub2.size() <= c) ub2.resize(c + 1, false);
-			ub2[c] = true;
+			const u32 a = std::min<u32>(js.a[i], (u32)bodies.size()), b = std::min<u32>(js.b[i], (u32)bodies.size());
+			const u32 c = std::max(a < bodies.size() ? nextLevel[a] : 0u, b < bodies.size() ? nextLevel[b] : 0u);
+			if (a < bodies.size()) nextLevel[a] = c + 1;
+			if (b < bodies.size()) nextLevel[b] = c + 1;
 			color[i] = c; numColors = std::max(numColors, c + 1);
 		}
+		numLevels = std::max(numLevels, numColors);
 		js.order.clear(); js.colorStart.assign(1, 0);
 		for (u32 c = 0; c < numColors; ++c)
 		{
@@ -442,26 +445,23 @@ void World::uploadJoints()
 		for (u32 i = 0; i <= n; ++i) rep[i] = i;
 		auto find = [&](u32 x) { while (rep[x] != x) { rep[x] = rep[rep[x]]; x = rep[x]; } return x; };
 		std::vector<uint4> table;
-		u32 numClasses = 0;
+		const u32 numClasses = numLevels; // class = level: the sweep runs the levels one after the other, whatever the types of their joints
 		for (u32 t = 0; t < MI_JOINT_TYPES; ++t)
 		{
 			JointSet& js = joints[t];
 			for (size_t c = 0; c + 1 < js.colorStart.size(); ++c)
-			{
 				for (u32 sidx = js.colorStart[c]; sidx < js.colorStart[c + 1]; ++sidx)
 				{
 					u32 i = js.order[sidx], a = js.a[i], b = js.b[i];
-					table.push_back(make_uint4(t | (numClasses << 8), sidx, a, b));
+					table.push_back(make_uint4(t | ((u32)c << 8), sidx, a, b));
 					u32 ra = find(a), rb = find(b);
 					if (ra != rb) { if (ra < rb) rep[rb] = ra; else rep[ra] = rb; }
 				}
-				if (js.colorStart[c + 1] > js.colorStart[c]) ++numClasses;
-			}
 		}
 		for (u32 i = 0; i < n; ++i) rep[i] = find(i);
 		clNumJoints = (u32)table.size(); clNumJointClasses = numClasses;
 		clJointsInCluster = clNumJoints > 0 && numClasses <= CL_MAX_JOINT_CLASSES;
-		if (getenv("MI_CLUSTER_DEBUG")) fprintf(stderr, "[mi_physics] joints: %u in %u (type, colour) classes -> %s\n", clNumJoints, numClasses, clJointsInCluster ? "inside the cluster sweep" : "own launches");
+		if (getenv("MI_CLUSTER_DEBUG")) fprintf(stderr, "[mi_physics] joints: %u in %u levels -> %s\n", clNumJoints, numClasses, clJointsInCluster ? "inside the cluster sweep" : "own launches");
 		clRep.ensure(n + 1, stream); clJointTable.ensure(std::max<size_t>(table.size(), 1), stream);
 		MI_CHECK(hipMemcpyAsync(clRep.p, rep.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, stream));
 		if (!table.empty()) MI_CHECK(hipMemcpyAsync(clJointTable.p, table.data(), sizeof(uint4) * table.size(), hipMemcpyHostToDevice, stream));
