@@ -55,7 +55,7 @@ def cpu_baseline(scene, transforms, velocities, first_step, seconds=12.0, max_st
 def pmc_traffic(contacts):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes of this round (profiles/), scaled to this run's
     contact count: a STATIC figure, labelled so (the counters need their own rocprofv3 passes and cannot be read inside this run)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_k_cl_solve.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_k_cl_solve.json")
     try:
         with open(path) as f:
             p = json.load(f)

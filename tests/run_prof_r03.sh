@@ -1,12 +1,19 @@
-# Round-3 profile collection (run on the GPU box from the repo root): kernel trace of the driver's bench command, busy/idle per step.
+# Round-3 profile collection (run on the GPU box from the repo root).  Kernel trace + PMC passes of the DRIVER's bench command
+# (bench.py --steps 20 --warmup 5), a kernel trace of the default window, config 4, and the bench lines themselves.
 set -e
 mkdir -p gpurun_out/r03
-cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+timeout -k 10 400 python bench.py --steps 20 --warmup 5 > gpurun_out/r03/bench_c3_driver.json 2> gpurun_out/r03/bench_c3_driver.err
+timeout -k 10 400 python bench.py --no-cpu-baseline > gpurun_out/r03/bench_c3_default.json 2> gpurun_out/r03/bench_c3_default.err
+timeout -k 10 200 python bench.py --workload c4 --no-cpu-baseline > gpurun_out/r03/bench_c4.json 2> gpurun_out/r03/bench_c4.err
+cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03/stats -o c3 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r03/stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03/stats_c4 -o c4 -- python3 $R/bench.py --workload c4 --no-cpu-baseline > $R/gpurun_out/r03/stats_c4.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r03/pmc_fetch -o c3 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r03/pmc_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r03/pmc_write -o c3 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r03/pmc_write.log 2>&1
 cd $R
-T=$(ls gpurun_out/r03/stats/*/c3_kernel_trace.csv 2>/dev/null | head -1); [ -z "$T" ] && T=$(ls gpurun_out/r03/stats/c3_kernel_trace.csv)
-python tests/trace_gaps.py $T 20 > gpurun_out/r03/c3_last20.txt
-S=$(ls gpurun_out/r03/stats/*/c3_kernel_stats.csv 2>/dev/null | head -1); [ -z "$S" ] && S=$(ls gpurun_out/r03/stats/c3_kernel_stats.csv)
-python tests/prof_summary.py $S 45 > gpurun_out/r03/c3_kernel_summary.txt
-cat gpurun_out/r03/c3_last20.txt; tail -1 gpurun_out/r03/stats.log | cut -c1-300
+python tests/trace_gaps.py gpurun_out/r03/stats/c3_kernel_trace.csv 20 > gpurun_out/r03/c3_last20.txt
+python tests/prof_summary.py gpurun_out/r03/stats/c3_kernel_stats.csv 45 > gpurun_out/r03/c3_kernel_summary.txt
+python tests/prof_summary.py gpurun_out/r03/stats_c4/c4_kernel_stats.csv 25 > gpurun_out/r03/c4_kernel_summary.txt
+(python tests/pmc_summary.py gpurun_out/r03/pmc_fetch/c3_counter_collection.csv 20; python tests/pmc_summary.py gpurun_out/r03/pmc_write/c3_counter_collection.csv 20) 2>&1 | grep -E "kernel|k_cl_solve|k_epa|k_pairs" > gpurun_out/r03/pmc_summary.txt || true
+cat gpurun_out/r03/c3_last20.txt | head -5; cat gpurun_out/r03/pmc_summary.txt; tail -c 600 gpurun_out/r03/bench_c3_driver.json
