@@ -1,24 +1,26 @@
 // Contact sweep around LDS-resident clusters ("K11-cluster"): the production contact solver.
 //
-// Why.  A Gauss-Seidel sweep over a proper colouring has (colours x iterations) ~ 20 x 30 = 600 dependent phases per step.  Across the
-// chip a phase boundary costs a launch (~5 us) or a tagged hand-over through L2 / the fabric (~2 us); inside ONE workgroup it
-// costs a barrier over LDS (~0.3 us).  So the world is cut into spatial clusters that one 1024-lane workgroup each solves
-// entirely out of LDS for all iterations, and only what a cut crosses goes through memory:
+// Why.  A Gauss-Seidel sweep over a proper colouring has (colours x iterations) ~ 25 x 30 dependent phases per step.  Across the
+// chip a phase boundary costs a launch (~5 us) or a tagged hand-over through L2 / the fabric (~2.5 us); inside ONE workgroup it
+// costs a barrier over LDS (~0.25 us with the step's work).  So the world is cut into spatial clusters that one 512-lane workgroup
+// each solves entirely out of LDS and registers for all iterations, and only what a cut crosses goes through memory:
 //
-//   phase 0..P-1 ("partitions"): the bodies are ordered along a Morton curve (each phase its own, shifted, curve) and the curve is
-//       chunked by weight into tasks of <= ~960 manifolds; a manifold whose two bodies fall into the same chunk is INTERIOR to
-//       that task.  Phase p only looks at what phases < p left over, so its chunks cover ever larger volumes and swallow the
-//       earlier phases' cut surfaces.
-//   phase P ("rest"): whatever is cut in every partition (a few hundred manifolds at 200k) forms one last task.
+//   phase 0..P-1 ("curve phases", default P = 2): the bodies are ordered along a Morton curve (each phase its own, shifted, curve)
+//       and the curve is chunked by weight into tasks of ~1000 (later phases ~500) contacts; a manifold whose two bodies fall into
+//       the same chunk is INTERIOR to that task.  Phase p only looks at what phases < p left over.
+//   phase P ("component phase"): what the curves leave over is not cut again; its connected components are dealt whole to the tasks
+//       of one more phase.  A rest task (phase CL_MAX_PARTS) only takes what that cannot place (nothing, in practice).
 //
-// Tasks of one phase share no body, so they run concurrently, one workgroup each; a workgroup runs its (at most one per phase)
-// tasks in phase order, iteration after iteration.  Inside a task the manifolds are coloured locally (in LDS, by the task's
-// workgroup: k_cl_color) and swept colour by colour with a workgroup barrier in between; body velocities live in LDS for the whole
-// launch, the first contact row of the first task's manifolds in registers, all other rows in LDS (global memory only when the
-// LDS budget is exceeded).  A body touched in more than one phase is handed from task to task through the tagged 2 x 16-byte
-// records of the old dataflow sweep (sc1 store / sc1 poll, MI355X_MICROARCH.md "tagged granules"): with d = number of phases that
-// touch the body, the task of phase p is its r-th user, r = popcount(phaseMask & ((1 << p) - 1)), waits for turn
-// epoch + it * d + r and publishes + 1.  Every wait points to a strictly earlier (iteration, phase): no cycles.
+// Tasks of one phase share no body, so they run concurrently, one workgroup each; a workgroup runs its (at most two per phase)
+// tasks in phase order, iteration after iteration.  Inside a task the CONTACTS are coloured locally (k_cl_color: a manifold with K
+// contacts takes K consecutive colours) and swept colour by colour with a workgroup barrier in between, four lanes (a quad) per
+// contact row: lane q owns one of vA, wA, vB, wB in LDS and the row's vectors for it, the row velocity is summed inside the quad with
+// two DPP adds.  Body velocities live in LDS for the whole launch, the rows of the workgroup's first task in registers
+// (CLQ_SETS x CLQ_QUADS contacts), all other rows in LDS in the same lane-private format, global scratch only beyond that.  A body
+// touched in more than one phase is handed from task to task through tagged 2 x 16-byte records (sc1 store / sc1 poll,
+// MI355X_MICROARCH.md "tagged granules"): with d = number of phases that touch the body, the task of phase p is its r-th user,
+// r = popcount(phaseMask & ((1 << p) - 1)), waits for turn epoch + it * d + r and publishes + 1.  Every wait points to a strictly
+// earlier (iteration, phase): no cycles.
 //
 // The result is a Gauss-Seidel sweep in the sequential order (phase, task, local colour, position) — the order
 // mi_debug_read_schedule reports and the CPU oracle follows — with bit-identical arithmetic to the launch-per-colour sweep.
