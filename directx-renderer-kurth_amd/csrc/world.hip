@@ -656,11 +656,17 @@ void World::recoverFlow()
 	// with one more partition phase; anything else = a lane timed out (GPU shared with another persistent kernel): stay away for a while
 	u32 why = hCounters[CTR_FLOW_STATUS];
 	if (getenv("MI_CLUSTER_DEBUG"))
-		fprintf(stderr, "[mi_physics] step %u: cluster sweep gave up: status %u, build status %u, parts %u, tasks %u %u %u %u %u, manifolds %u %u %u %u %u (active %u), remain %u %u %u %u %u; components: listed %u tasks %u weight %u ends disagree %u largest too-big %u\n", stats.numInternalSteps, why,
-			hCounters[CTR_CL_STATUS], clusterParts, hCounters[CTR_CL_NUM_TASKS], hCounters[CTR_CL_NUM_TASKS + 1], hCounters[CTR_CL_NUM_TASKS + 2], hCounters[CTR_CL_NUM_TASKS + 3], hCounters[CTR_CL_NUM_TASKS + 4],
-			hCounters[CTR_CL_PHASE_COUNT], hCounters[CTR_CL_PHASE_COUNT + 1], hCounters[CTR_CL_PHASE_COUNT + 2], hCounters[CTR_CL_PHASE_COUNT + 3], hCounters[CTR_CL_PHASE_COUNT + 4], hCounters[CTR_NUM_ACTIVE],
-			hCounters[CTR_CL_REMAIN + 1], hCounters[CTR_CL_REMAIN + 2], hCounters[CTR_CL_REMAIN + 3], hCounters[CTR_CL_REMAIN + 4], hCounters[CTR_CL_REMAIN + 5],
-			hCounters[CTR_CL_LEFT], hCounters[CTR_CL_LEFT + 1], hCounters[CTR_CL_LEFT + 2], hCounters[CTR_CL_LEFT + 3], hCounters[CTR_CL_LEFT + 4]);
+	{
+		// (a fresh copy: hCounters is one step old when the give-up is noticed outside a step, and nothing of the next step's setup has run yet)
+		std::vector<u32> c(CTR_WORDS);
+		(void)hipMemcpyAsync(c.data(), dCounters.p, CTR_WORDS * sizeof(u32), hipMemcpyDeviceToHost, stream);
+		(void)hipStreamSynchronize(stream);
+		fprintf(stderr, "[mi_physics] step %u: cluster sweep gave up: status %u, build status %u, parts %u, tasks %u %u %u %u %u, manifolds %u %u %u %u %u (active %u), remain %u %u %u %u %u; components: listed %u tasks %u weight %u ends disagree %u largest too-big %u; scratch rows %u\n", stats.numInternalSteps, c[CTR_FLOW_STATUS] | why,
+			c[CTR_CL_STATUS], clusterParts, c[CTR_CL_NUM_TASKS], c[CTR_CL_NUM_TASKS + 1], c[CTR_CL_NUM_TASKS + 2], c[CTR_CL_NUM_TASKS + 3], c[CTR_CL_NUM_TASKS + 4],
+			c[CTR_CL_PHASE_COUNT], c[CTR_CL_PHASE_COUNT + 1], c[CTR_CL_PHASE_COUNT + 2], c[CTR_CL_PHASE_COUNT + 3], c[CTR_CL_PHASE_COUNT + 4], c[CTR_NUM_ACTIVE],
+			c[CTR_CL_REMAIN + 1], c[CTR_CL_REMAIN + 2], c[CTR_CL_REMAIN + 3], c[CTR_CL_REMAIN + 4], c[CTR_CL_REMAIN + 5],
+			c[CTR_CL_LEFT], c[CTR_CL_LEFT + 1], c[CTR_CL_LEFT + 2], c[CTR_CL_LEFT + 3], c[CTR_CL_LEFT + 4], c[CTR_CL_SCRATCH]);
+	}
 	// (a world that keeps not fitting backs off: 4, 8, ... 256 steps of launch sweep between attempts)
 	if ((why & 64u) && !(why & 1u)) { clusterCooldown = std::min(256u, 4u << std::min(clusterFailStreak, 6u)); ++clusterFailStreak; if (!clusterPartsFixed && clusterParts < CL_MAX_PARTS) ++clusterParts; }
 	else clusterCooldown = 256;
