@@ -13,7 +13,17 @@ enum { EVENT_TRIGGER_ENTER = 0, EVENT_TRIGGER_LEAVE = 1, EVENT_COLLISION_BEGIN =
 #define PAIRSET_MAX_PROBES 2048u
 
 struct PairSetView { u64* cur; u64* prev; u32 mask, shift; };
-struct EventSink { EventRec* events; u32* counters; u32 capacity, step; };
+struct EventSink { EventRec* events; u32* counters; u32 capacity, step; const uint8_t* slabCode; };
+// Slab worlds (one rank per GPU): a pair near a cut is simulated — and its overlap sets are kept — on both ranks.  Exactly one of
+// them REPORTS its events: the rank that owns the pair's dynamic body with the lower index (for a trigger: the body).  That rank
+// always simulates both bodies while they touch (the partner is its ghost); the sets themselves are not filtered, so a pair that stays
+// in contact while its reporter changes hands raises nothing.  physics.cpp:1037-1178: one begin / end per pair.
+MI_DEV bool eventIsMine(const EventSink& sink, u32 bodyA, u32 bodyB, u32 nb)
+{
+	if (!sink.slabCode) return true;
+	u32 reporter = (bodyA < nb && bodyB < nb) ? min(bodyA, bodyB) : (bodyA < nb ? bodyA : bodyB);
+	return reporter >= nb || sink.slabCode[reporter] == MI_SLAB_OWNED;
+}
 
 MI_DEV u32 pairSetHash(u64 key, u32 shift) { return (u32)((key * 0x9E3779B97F4A7C15ull) >> shift); }
 // Returns true if this call inserted the key (exactly one caller per distinct key does).  A full table raises CTR_EVENT_OVERFLOW bit 1.

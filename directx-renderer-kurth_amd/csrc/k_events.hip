@@ -59,9 +59,9 @@ __global__ void __launch_bounds__(256) k_scan_previous_set(PairSetView set, Even
 	if (COLLISIONS)
 	{
 		u32 bodyA = colBody(colWorld[a]), bodyB = colBody(colWorld[b]);
-		eventWritePlain(sink, EVENT_COLLISION_END, a, b, bodyA < nb ? bodyA : 0xFFFFFFFFu, bodyB < nb ? bodyB : 0xFFFFFFFFu);
+		if (eventIsMine(sink, bodyA, bodyB, nb)) eventWritePlain(sink, EVENT_COLLISION_END, a, b, bodyA < nb ? bodyA : 0xFFFFFFFFu, bodyB < nb ? bodyB : 0xFFFFFFFFu);
 	}
-	else eventWritePlain(sink, EVENT_TRIGGER_LEAVE, a, b, 0xFFFFFFFFu, b);
+	else if (eventIsMine(sink, b, b, nb)) eventWritePlain(sink, EVENT_TRIGGER_LEAVE, a, b, 0xFFFFFFFFu, b);
 }
 
 static PairSetView viewOf(DevBuf<u64>* tables, u32 size, u32 cur)
@@ -69,7 +69,7 @@ static PairSetView viewOf(DevBuf<u64>* tables, u32 size, u32 cur)
 	PairSetView v; v.cur = tables[cur].p; v.prev = tables[cur ^ 1].p; v.mask = size - 1; v.shift = 64u - (u32)__builtin_ctz(size);
 	return v;
 }
-static EventSink sinkOf(World& w) { EventSink s = { (EventRec*)w.eventRing.p, w.dCounters.p, w.eventCap, w.stats.numInternalSteps }; return s; }
+EventSink sinkOf(World& w) { EventSink s = { (EventRec*)w.eventRing.p, w.dCounters.p, w.eventCap, w.stats.numInternalSteps, w.slabSize > 1 ? w.slabCode.p : nullptr }; return s; }
 
 void launch_trigger_events(World& w)
 {
@@ -96,6 +96,7 @@ __global__ void __launch_bounds__(256) k_collision_begin(u32* __restrict__ count
 	u64 key = ((u64)a << 32) | b;
 	if (!pairSetInsert(set.cur, set.mask, set.shift, key, counters)) return;
 	if (!emit || pairSetContains(set.prev, set.mask, set.shift, key)) return;
+	if (!eventIsMine(sink, ids.x, ids.y, nb)) return;
 	EventRec* e = eventAppend(sink);
 	if (!e) return;
 	ManifoldRec m = manifolds[slot];

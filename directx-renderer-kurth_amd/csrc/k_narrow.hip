@@ -7,6 +7,7 @@
 #include "world.h"
 #include <rocprim/rocprim.hpp>
 #include "events.h"
+EventSink sinkOf(World& w);
 #include <algorithm>
 
 void prim_sort_pairs_u32_u64(World& w, const u32* kin, u32* kout, const u64* vin, u64* vout, u32 n, u32 bits);
@@ -1195,7 +1196,7 @@ __global__ void __launch_bounds__(64) k_zone_overlap(u32* __restrict__ counters,
 	else if (triggers.cur)
 	{
 		u64 key = ((u64)zoneIndex << 32) | body;
-		if (pairSetInsert(triggers.cur, triggers.mask, triggers.shift, key, counters) && !pairSetContains(triggers.prev, triggers.mask, triggers.shift, key))
+		if (pairSetInsert(triggers.cur, triggers.mask, triggers.shift, key, counters) && !pairSetContains(triggers.prev, triggers.mask, triggers.shift, key) && eventIsMine(sink, body, body, nb))
 			eventWritePlain(sink, EVENT_TRIGGER_ENTER, zoneIndex, body, 0xFFFFFFFFu, body);
 	}
 }
@@ -1243,7 +1244,7 @@ void launch_zone_overlap(World& w, u32 numPairs)
 	if (!numPairs || (w.fields.empty() && w.triggers.empty())) return;
 	const u64* sortedPairs = (const u64*)w.pairsSorted.p;
 	PairSetView tv = { w.triggers.empty() ? nullptr : w.triggerSet[w.triggerCur].p, w.triggers.empty() ? nullptr : w.triggerSet[w.triggerCur ^ 1].p, w.triggerSetSize - 1, 64u - (u32)__builtin_ctz(w.triggerSetSize ? w.triggerSetSize : 2u) };
-	EventSink sink = { (EventRec*)w.eventRing.p, w.dCounters.p, w.eventCap, w.stats.numInternalSteps };
+	EventSink sink = sinkOf(w);
 	hipLaunchKernelGGL(k_zone_overlap, dim3((numPairs + 63) / 64), dim3(64), 0, w.stream, w.dCounters.p, sortedPairs, w.colWorld.p, w.hullInfo.p, w.hullVerts.p, w.nb,
 		w.fieldMask.p, w.fieldWords, tv, sink);
 }
