@@ -4,6 +4,7 @@
 // batch variant of the contact path (the AVX2 shape, :3451-3709) lives in owide.h and is the cpu_baseline.
 #pragma once
 #include "oshapes.h"
+#include "owidemath.h"
 #include <vector>
 
 namespace orc {
@@ -496,7 +497,7 @@ static inline void initializeHingeConstraint(hinge_constraint_update& out, const
 	if (in.minRotationLimit <= 0.f || in.maxRotationLimit >= 0.f || in.maxMotorTorque > 0.f)
 	{
 		vec3 localHingeCompareA = conjugate(globalA.rotation) * (globalB.rotation * in.localHingeTangentB);
-		float angle = atan2f(dot(localHingeCompareA, in.localHingeBitangentA), dot(localHingeCompareA, in.localHingeTangentA));
+		float angle = jointAtan2(jointDot(localHingeCompareA, in.localHingeBitangentA), jointDot(localHingeCompareA, in.localHingeTangentA)); // (wide path: constraints.cpp:1545, polynomial atan2)
 		bool minLimitViolated = in.minRotationLimit <= 0.f && angle <= in.minRotationLimit;
 		bool maxLimitViolated = in.maxRotationLimit >= 0.f && angle >= in.maxRotationLimit;
 		out.solveLimit = minLimitViolated || maxLimitViolated;
@@ -611,14 +612,14 @@ static inline void initializeConeTwistConstraint(cone_twist_constraint_update& o
 	quat btoa = conjugate(globalA.rotation) * globalB.rotation;
 	vec3 localLimitAxisA = in.localLimitAxisA;
 	vec3 localLimitAxisCompareA = btoa * in.localLimitAxisB;
-	quat swingRotation = rotateFromTo(localLimitAxisA, localLimitAxisCompareA);
+	quat swingRotation = jointRotateFromTo(localLimitAxisA, localLimitAxisCompareA); // (wide path: constraints.cpp:2258-2272)
 	vec3 twistTangentA = swingRotation * in.localLimitTangentA;
 	vec3 twistBitangentA = swingRotation * in.localLimitBitangentA;
 	vec3 localLimitTangentCompareA = btoa * in.localLimitTangentB;
-	float twistAngle = atan2f(dot(localLimitTangentCompareA, twistBitangentA), dot(localLimitTangentCompareA, twistTangentA));
+	float twistAngle = jointAtan2(jointDot(localLimitTangentCompareA, twistBitangentA), jointDot(localLimitTangentCompareA, twistTangentA));
 
 	vec3 swingAxis; float swingAngle;
-	getAxisRotation(swingRotation, swingAxis, swingAngle);
+	jointGetAxisRotation(swingRotation, swingAxis, swingAngle);
 	if (swingAngle < 0.f) { swingAngle *= -1.f; swingAxis *= -1.f; }
 
 	out.solveSwingLimit = in.swingLimit >= 0.f && swingAngle >= in.swingLimit;
@@ -639,7 +640,7 @@ static inline void initializeConeTwistConstraint(cone_twist_constraint_update& o
 	{
 		out.maxSwingMotorImpulse = in.maxSwingMotorTorque * dt;
 		out.swingMotorImpulse = 0.f;
-		float axisX = cosf(in.swingMotorAxis), axisY = sinf(in.swingMotorAxis);
+		float axisX = jointCos(in.swingMotorAxis), axisY = jointSin(in.swingMotorAxis);
 		vec3 localSwingMotorAxis = axisX * in.localLimitTangentA + axisY * in.localLimitBitangentA;
 		if (in.swingMotorType == constraint_velocity_motor)
 		{
@@ -650,11 +651,11 @@ static inline void initializeConeTwistConstraint(cone_twist_constraint_update& o
 		{
 			float targetAngle = in.swingMotorVelocity;
 			if (in.swingLimit >= 0.f) { targetAngle = clampf(targetAngle, -in.swingLimit, in.swingLimit); }
-			vec3 localTargetDirection = quat(localSwingMotorAxis, targetAngle) * localLimitAxisA;
-			vec3 localSwingMotorAxis2 = noz(cross(localLimitAxisCompareA, localTargetDirection));
+			vec3 localTargetDirection = jointQuatAxisAngle(localSwingMotorAxis, targetAngle) * localLimitAxisA;
+			vec3 localSwingMotorAxis2 = jointNoz(wideJointMath() ? wcross(localLimitAxisCompareA, localTargetDirection) : cross(localLimitAxisCompareA, localTargetDirection));
 			out.globalSwingMotorAxis = globalA.rotation * localSwingMotorAxis2;
-			float cosAngle = dot(localTargetDirection, localLimitAxisCompareA);
-			float deltaAngle = acosf(clamp01(cosAngle));
+			float cosAngle = jointDot(localTargetDirection, localLimitAxisCompareA);
+			float deltaAngle = jointAcos(clamp01(cosAngle));
 			out.swingMotorVelocity = (dt > ORC_DT_THRESHOLD) ? (deltaAngle * invDt * 0.2f) : 0.f;
 		}
 		out.swingMotorImpulseToAngularVelocityA = globalA.invInertia * out.globalSwingMotorAxis;

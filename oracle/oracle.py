@@ -75,6 +75,7 @@ def _lib(avx2=False):
                      "orc_terrain_slot_mismatch", "orc_terrain_contacts", "orc_add_cloth", "orc_cloth_num_particles", "orc_cloth_num_constraints", "orc_add_force_field", "orc_add_trigger", "orc_add_force_field_collider", "orc_add_trigger_collider", "orc_drain_events"):
             getattr(lib, name).restype = C.c_uint32
         lib.orc_heightmap_height_at.restype = C.c_float
+        lib.orc_poly_trig.restype = C.c_float
         _libs[key] = lib
     return _libs[key]
 
@@ -289,6 +290,17 @@ class OracleWorld:
     def set_wide_rsqrt(self, on=True):
         """The 8-lane solver's noz with the host's rsqrtss estimate (the reference's AVX2 semantics) instead of exact 1/sqrt.  Process-wide."""
         self.lib.orc_set_wide_rsqrt(int(on))
+
+    def set_wide_joint_math(self, on=True):
+        """Joint initialisation (hinge / cone-twist limit and motor angles) with the reference's wide math — polynomial cos / sin /
+        atan2 / acos (core/simd.h:28-49, 122-164), rsqrt-based normalisation, wide rotateFromTo / getAxisRotation — instead of the
+        scalar path's libm calls: the "AVX2 semantics" of constraints.cpp:1309-1777, 2072-2634.  Process-wide."""
+        self.lib.orc_set_wide_joint_math(int(on))
+
+    def poly_trig(self, which, a, b=0.0):
+        """The reference's polynomial cos (0) / sin (1) / atan2(a, b) (2) / acos (3) for one float."""
+        self.lib.orc_poly_trig.restype = C.c_float
+        return float(self.lib.orc_poly_trig(int(which), C.c_float(a), C.c_float(b)))
 
     def stage_seconds(self, reset=True):
         """Cumulative wall time per stage since the last reset: colliders + broadphase, narrowphase, forces + constraint setup, solve, integration."""

@@ -12,22 +12,10 @@
 #pragma once
 #include "oconstraints.h"
 
-#if defined(__SSE__)
-#include <xmmintrin.h>
-#endif
-
 namespace orc {
 
 static const u32 WIDE = 8;
-inline bool& wideApproxRsqrt() { static bool on = false; return on; }
-static inline float rsqrtEstimate(float x)
-{
-#if defined(__SSE__)
-	return _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set_ss(x)));
-#else
-	return 1.f / sqrtf(x);
-#endif
-}
+// (wideApproxRsqrt() / rsqrtEstimate(): owidemath.h)
 
 // constraints.h:641-662 (30 float rows x 8 + 2 x 8 ids)
 struct alignas(32) simd_collision_constraint_batch

@@ -1521,6 +1521,10 @@ int orc_step_internal(world* w, u32 iterations, u32 mode, float dt) { physicsSte
 void orc_set_custom_order(world* w, const u32* order, u32 n) { w->customOrder.assign(order, order + n); }
 void orc_set_row_form(world* w, int on) { w->rowForm = on != 0; w->scalarRowForm = on != 0; }
 void orc_set_wide_rsqrt(int on) { wideApproxRsqrt() = on != 0; }
+// Joint initialisation with the reference's wide math (polynomial trig, rsqrt-based normalisation: owidemath.h) — row a33.
+void orc_set_wide_joint_math(int on) { wideJointMath() = on != 0; }
+// The polynomial functions themselves, for the tests (which: 0 cos, 1 sin, 2 atan2(a, b), 3 acos).
+float orc_poly_trig(int which, float a, float b) { return which == 0 ? polyCos(a) : which == 1 ? polySin(a) : which == 2 ? polyAtan2(a, b) : polyAcos(a); }
 void orc_stage_seconds(world* w, double* out5, int reset) { for (int i = 0; i < 5; ++i) { out5[i] = w->stageSeconds[i]; if (reset) w->stageSeconds[i] = 0; } }
 // Follow mode (see struct world): ordered candidate pairs + manifold execution order; n = 0 switches it off.
 void orc_set_follow(world* w, const u32* pairs2, u32 numPairs, const u32* slotOrder, u32 numOrder)

@@ -441,6 +441,63 @@ def test_avx2_semantics_delta(oracle):
     assert deltas and 0.0 < deltas[0] <= 4e-4
 
 
+def test_polynomial_trig_of_the_wide_paths(oracle):
+    """The reference's wide paths evaluate cos / sin / atan2 / acos with short polynomials (core/simd.h:28-49, 122-164).  Their
+    restatement against libm: the known shapes of the approximations (exact at the quadrant points, errors of the published size),
+    so that a slip in a coefficient or in the quadrant logic shows."""
+    w = oracle.OracleWorld()
+    xs = np.linspace(-7.0, 7.0, 2801, dtype=np.float32)
+    cos_err = max(abs(w.poly_trig(0, float(x)) - np.cos(np.float64(x))) for x in xs)
+    sin_err = max(abs(w.poly_trig(1, float(x)) - np.sin(np.float64(x))) for x in xs)
+    assert 2e-4 < cos_err < 1.2e-3 and 2e-4 < sin_err < 1.2e-3, (cos_err, sin_err)      # the parabola pair with the 0.225 correction: ~1e-3
+    assert abs(w.poly_trig(0, 0.0) - 1.0) < 1e-6 and abs(w.poly_trig(0, float(np.float32(np.pi))) + 1.0) < 1e-5 and abs(w.poly_trig(1, 0.0)) < 1e-6
+    angles = np.linspace(-np.pi, np.pi, 1441)[1:-1]
+    atan_err = max(abs(w.poly_trig(2, float(np.float32(np.sin(a))), float(np.float32(np.cos(a)))) - a) for a in angles)
+    assert 5e-4 < atan_err < 3e-3, atan_err                                                # rational first-quadrant fit, b = 0.596227
+    for y, x, want in ((0.0, 1.0, 0.0), (1.0, 0.0, np.pi / 2), (-1.0, 0.0, -np.pi / 2), (1.0, 1.0, np.pi / 4), (1.0, -1.0, 3 * np.pi / 4), (-1.0, -1.0, -3 * np.pi / 4)):
+        assert abs(w.poly_trig(2, y, x) - want) < 2e-6, (y, x, w.poly_trig(2, y, x), want)   # exact on the axes and diagonals
+    cs = np.linspace(-1.0, 1.0, 2001, dtype=np.float32)
+    acos_err = max(abs(w.poly_trig(3, float(c)) - np.arccos(np.float64(c))) for c in cs)
+    assert 1e-5 < acos_err < 1e-4, acos_err                                                # the cubic * sqrt(1 - x) form: ~7e-5
+    print("polynomial trig of the wide paths against libm: cos %.1e, sin %.1e, atan2 %.1e rad, acos %.1e rad" % (cos_err, sin_err, atan_err, acos_err))
+
+
+def test_avx2_semantics_delta_of_the_joints(oracle):
+    """Row a33 for the joints: the reference's 8-wide hinge and cone-twist initialisation (constraints.cpp:1309-1777, 2072-2634)
+    computes the hinge angle, the twist angle, the swing rotation and the motor targets with the polynomial functions above and
+    rsqrt-based normalisation; its scalar path calls libm.  BASELINE config 4 (256 ragdolls) in the oracle's 8-lane mode (joints in
+    the scheduler's batch order, contacts 8 wide), once with each, per step from identical inputs: the distance between the two is
+    the joints' "AVX2 semantics" delta.  The angles only matter where a limit is violated or a motor runs: the delta is exactly zero
+    while the ragdolls fall freely, ~7.5e-3 rad/s once limits engage (an angle error of up to ~3e-3 rad in a violated limit changes
+    its bias velocity by 3e-3 * beta / dt ~ 2e-2), and a handful of bodies per step differ by whole rad/s: their limit is just
+    violated with one angle and just not with the other, so one side solves the limit row and the other does not."""
+    from directx_renderer_kurth_amd import scenes
+    scene = scenes.by_name("c4")
+    exact = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_WIDE8))
+    wide = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_WIDE8))
+    first, typical, flips, zero_steps = None, [], 0, 0
+    try:
+        for i in range(40):
+            exact.set_wide_joint_math(False); exact.step_internal(scene.dt)
+            wide.set_wide_joint_math(True); wide.step_internal(scene.dt)
+            ve, vw = exact.velocities(), wide.velocities()
+            d = np.abs(ve - vw).max(axis=1)
+            if d.max() == 0.0:
+                zero_steps += 1
+            else:
+                if first is None:
+                    first = (i, float(d.max()))
+                typical.append(float(np.median(d[d > 0])))
+                flips = max(flips, int((d > 0.1).sum()))
+            wide.write_state(exact.transforms(1), ve)          # per-step delta: both continue from the exact world's state
+    finally:
+        exact.set_wide_joint_math(False)
+    print("AVX2-semantics delta of the joints on config 4 (3 584 bodies), per step from identical inputs: zero in %d of 40 steps; first non-zero at step %d: %.1e rad/s; "
+          "median body delta in the other steps %.1e ... %.1e; at most %d bodies per step beyond 0.1 (a limit engaged on one side only)"
+          % (zero_steps, first[0], first[1], min(typical), max(typical), flips))
+    assert first is not None and 1e-4 < first[1] < 5e-2 and max(typical) < 2e-2 and flips < 0.03 * exact.velocities().shape[0] and zero_steps > 5
+
+
 def test_oracle_under_sanitizers():
     """The CPU restatement under AddressSanitizer + UndefinedBehaviourSanitizer (oracle/san_driver.cpp: mixed shapes, three joint
     kinds, the three solver modes, 90 steps each).  GPU sanitizers are not available on the MI355X pool; the oracle shares the
