@@ -287,6 +287,11 @@ class OracleWorld:
         """Custom-order contact solves in the device's row form (default) or with the reference formula."""
         self.lib.orc_set_row_form(self.w, int(on))
 
+    def set_scalar_row_form(self, on=True):
+        """SOLVER_SCALAR (the reference's emission order) with the row-form arithmetic instead of the reference formula: lets a test
+        measure the distance between the two on one order.  Off by default, and not touched by set_row_form."""
+        self.lib.orc_set_scalar_row_form(self.w, int(on))
+
     def set_wide_rsqrt(self, on=True):
         """The 8-lane solver's noz with the host's rsqrtss estimate (the reference's AVX2 semantics) instead of exact 1/sqrt.  Process-wide."""
         self.lib.orc_set_wide_rsqrt(int(on))

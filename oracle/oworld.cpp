@@ -1519,7 +1519,8 @@ int orc_set_velocity(world* w, u32 b, const float* lin, const float* ang)
 int orc_step(world* w, float* timer, const physics_settings* settings, u32 mode, float dt) { physicsStep(*w, *timer, *settings, mode, dt); return 0; }
 int orc_step_internal(world* w, u32 iterations, u32 mode, float dt) { physicsStepInternal(*w, iterations, mode, dt); return 0; }
 void orc_set_custom_order(world* w, const u32* order, u32 n) { w->customOrder.assign(order, order + n); }
-void orc_set_row_form(world* w, int on) { w->rowForm = on != 0; w->scalarRowForm = on != 0; }
+void orc_set_row_form(world* w, int on) { w->rowForm = on != 0; }                  // custom-order (follow) solves: the device's row form (default) or the reference formula
+void orc_set_scalar_row_form(world* w, int on) { w->scalarRowForm = on != 0; }     // the scalar solver in emission order, in row form (default: the reference formula)
 void orc_set_wide_rsqrt(int on) { wideApproxRsqrt() = on != 0; }
 // Joint initialisation with the reference's wide math (polynomial trig, rsqrt-based normalisation: owidemath.h) — row a33.
 void orc_set_wide_joint_math(int on) { wideJointMath() = on != 0; }

@@ -390,7 +390,7 @@ def test_row_form_against_reference_formula(oracle, name, steps):
     from directx_renderer_kurth_amd import scenes
     scene = scenes.by_name(name)
     a = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_SCALAR))
-    b = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_SCALAR)); b.set_row_form(True)
+    b = scene.instantiate(oracle.OracleWorld(solver=oracle.SOLVER_SCALAR)); b.set_scalar_row_form(True)
     deltas = _first_contact_deltas(a, b, scene, steps)
     dpos = float(np.abs(a.transforms(1)[:, :3] - b.transforms(1)[:, :3]).max())
     print(name, "row form vs reference formula: relative velocity difference over the first contact steps", ["%.1e" % d for d in deltas], "| positions after %d steps: %.2e m" % (steps, dpos))
