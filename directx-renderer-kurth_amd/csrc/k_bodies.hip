@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) k_build_colliders(u32 nb, const u32* __re
 	__syncthreads();
 	if (threadIdx.x == 0 && sMax) atomicMax(&counters[CTR_CELL_SIZE], sMax);
 	if (threadIdx.x < 7) sapPartial[(size_t)blockIdx.x * 7 + threadIdx.x] = ((sAcc[0][threadIdx.x] + sAcc[1][threadIdx.x]) + sAcc[2][threadIdx.x]) + sAcc[3][threadIdx.x];
-	for (u32 h = gid; h < hashTableSize + 3u; h += stride) { if (h < hashTableSize) cellStart[h] = 0xFFFFFFFFu; cellCount[h] = 0u; } // EMPTY_CELL; bucket sizes (+ the 'large' and 'simulated elsewhere' buckets)
+	for (u32 h = gid; h < hashTableSize + 3u; h += stride) { if (h < hashTableSize) cellStart[2 * h] = 0xFFFFFFFFu; cellCount[h] = 0u; } // (cellStart: {first, end} per bucket) // EMPTY_CELL; bucket sizes (+ the 'large' and 'simulated elsewhere' buckets)
 }
 
 u32 active_grid(u32 estimate, u32 total) { return (u32)((std::min<u64>(total, (u64)estimate + estimate / 8u + 2048u) + 255u) / 256u); } // workgroups of 256 for a kernel that strides over an active list

@@ -24,6 +24,10 @@ MI_DEV i32 cellCoord(float v, float invCell)
 	c = fminf(fmaxf(c, -(float)(CELL_BIAS - 2)), (float)(CELL_BIAS - 2));
 	return (i32)c + CELL_BIAS;
 }
+// What a candidate in a visited bucket is checked against (buckets are shared by the cells that hash alike): the low 10 bits of the
+// three cell coordinates.  Two different cells among a collider's 27 neighbours differ in these bits; a far cell that agrees in all
+// of them is more than a thousand cells away and fails the box test.
+MI_DEV u32 cellTag(i32 ix, i32 iy, i32 iz) { return ((u32)ix & 0x3FFu) | (((u32)iy & 0x3FFu) << 10) | (((u32)iz & 0x3FFu) << 20); }
 MI_DEV bool aabbOverlap(float4 amin, float4 amax, float4 bmin, float4 bmax)
 {
 	if (amax.x < bmin.x || amin.x > bmax.x) return false;
@@ -80,7 +84,7 @@ __global__ void __launch_bounds__(256) k_cell_rank(const u32* __restrict__ count
 
 __global__ void __launch_bounds__(256) k_gather_sorted(u32 hashMask, const u32* __restrict__ hashSorted, const u32* __restrict__ idxSorted,
 	const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax, u32* __restrict__ counters,
-	u64* __restrict__ sCellKey, float4* __restrict__ sMin, float4* __restrict__ sMax, u32* __restrict__ cellStart, u32* __restrict__ cellEnd)
+	float4* __restrict__ sBox, u32* __restrict__ cellRange)
 {
 	const u32 nc = counters[CTR_ACTIVE_COLS];
 	float cell = fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f) * 1.001f;
@@ -90,15 +94,15 @@ __global__ void __launch_bounds__(256) k_gather_sorted(u32 hashMask, const u32* 
 		u32 idx = idxSorted[t];
 		u32 h = hashSorted[t];
 		float4 mn = aabbMin[idx], mx = aabbMax[idx];
+		mx.w = __uint_as_float(cellTag(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell)));
 		mn.w = __uint_as_float(idx);
-		sMin[t] = mn; sMax[t] = mx;
-		sCellKey[t] = packCell(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell));
+		sBox[2 * t] = mn; sBox[2 * t + 1] = mx; // one 32-byte record per sorted position: a candidate test is ONE cache line (three arrays were three)
 		u32 hPrev = (t > 0) ? hashSorted[t - 1] : 0xFFFFFFFFu;
 		u32 hNext = (t + 1 < nc) ? hashSorted[t + 1] : 0xFFFFFFFFu;
 		if (h <= hashMask)
 		{
-			if (hPrev != h) cellStart[h] = t;
-			if (hNext != h) cellEnd[h] = t + 1;
+			if (hPrev != h) cellRange[2 * h] = t;
+			if (hNext != h) cellRange[2 * h + 1] = t + 1;
 		}
 		else if (hPrev != h) { counters[h == hashMask + 1 ? CTR_FIRST_LARGE : CTR_FIRST_INACTIVE] = t; }
 	}
@@ -117,8 +121,7 @@ __global__ void __launch_bounds__(256) k_gather_sorted(u32 hashMask, const u32* 
 #define PAIR_LANES 16
 enum { MODE_SLAB = 0, MODE_WRITE = 1 };
 template <int MODE>
-__global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* __restrict__ sCellKey, const float4* __restrict__ sMin, const float4* __restrict__ sMax,
-	const u32* __restrict__ cellStart, const u32* __restrict__ cellEnd, u32* __restrict__ counters,
+__global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const float4* __restrict__ sBox, const uint2* __restrict__ cellRange, u32* __restrict__ counters,
 	u32* __restrict__ pairCount, const u32* __restrict__ pairOffset, uint2* __restrict__ out, u32 pairCap)
 {
 	u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -131,25 +134,25 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* 
 	float4 amin = make_float4(0.f, 0.f, 0.f, 0.f), amax = amin;
 	u32 me = 0;
 	// this lane's candidate range [s, e) and what a candidate must match
-	u32 s = 0, e = 0; u64 nkey = 0; bool checkKey = false;
+	u32 s = 0, e = 0; u32 ntag = 0; bool checkKey = false;
 	if (live)
 	{
-		amin = sMin[t]; amax = sMax[t];
+		amin = sBox[2 * t]; amax = sBox[2 * t + 1];
 		me = __float_as_uint(amin.w);
 		if (t >= firstLarge) { if (g == 0) { s = firstLarge; e = t; } }
 		else if (g == 14) { s = firstLarge; e = nEnd; }
 		else if (g < 14)
 		{
-			u64 key = sCellKey[t];
-			i32 ix = (i32)(key & CELL_MASK), iy = (i32)((key >> 21) & CELL_MASK), iz = (i32)((key >> 42) & CELL_MASK);
+			const float invCell = 1.f / (fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f) * 1.001f); // (as k_gather_sorted computes it)
+			i32 ix = cellCoord(amin.x, invCell), iy = cellCoord(amin.y, invCell), iz = cellCoord(amin.z, invCell);
 			i32 o = 13 + (i32)g; // offsets (dz,dy,dx) >= (0,0,0) in lexicographic order: own cell first, then the forward half
 			i32 dz = o / 9 - 1, dy = (o / 3) % 3 - 1, dx = o % 3 - 1;
-			nkey = packCell(ix + dx, iy + dy, iz + dz);
-			u32 h = hashCell(nkey, hashMask);
-			u32 cs = cellStart[h];
-			if (cs != EMPTY_CELL)
+			ntag = cellTag(ix + dx, iy + dy, iz + dz);
+			u32 h = hashCell(packCell(ix + dx, iy + dy, iz + dz), hashMask);
+			uint2 range = cellRange[h];
+			if (range.x != EMPTY_CELL)
 			{
-				s = cs; e = cellEnd[h];
+				s = range.x; e = range.y;
 				if (g == 0) e = min(e, t); // own cell: only partners sorted before me
 				checkKey = true;           // other cells may share the hash bucket
 			}
@@ -159,9 +162,9 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* 
 	u32 hit0 = 0, hit1 = 0, hit2 = 0, hit3 = 0; // the first four partners of this lane stay in registers: the write pass then needs no second visit
 	for (u32 u = s; u < e; ++u)
 	{
-		if (checkKey && sCellKey[u] != nkey) continue;
-		float4 bmin = sMin[u];
-		if (aabbOverlap(amin, amax, bmin, sMax[u]))
+		float4 bmin = sBox[2 * u], bmax = sBox[2 * u + 1];
+		if (checkKey && __float_as_uint(bmax.w) != ntag) continue;
+		if (aabbOverlap(amin, amax, bmin, bmax))
 		{
 			u32 partner = __float_as_uint(bmin.w);
 			if (n == 0) hit0 = partner; else if (n == 1) hit1 = partner; else if (n == 2) hit2 = partner; else if (n == 3) hit3 = partner;
@@ -188,9 +191,9 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const u64* 
 	}
 	for (u32 u = s; u < e; ++u)
 	{
-		if (checkKey && sCellKey[u] != nkey) continue;
-		float4 bmin = sMin[u];
-		if (!aabbOverlap(amin, amax, bmin, sMax[u])) continue;
+		float4 bmin = sBox[2 * u], bmax = sBox[2 * u + 1];
+		if (checkKey && __float_as_uint(bmax.w) != ntag) continue;
+		if (!aabbOverlap(amin, amax, bmin, bmax)) continue;
 		if (pos < room && (MODE == MODE_SLAB || base + pos < pairCap)) out[base + pos] = make_uint2(me, __float_as_uint(bmin.w));
 		++pos;
 	}
@@ -280,10 +283,10 @@ void launch_broadphase_count(World& w)
 	hipLaunchKernelGGL(k_cell_place, grid, block, 0, w.stream, w.dCounters.p, w.actCols.p, w.hashKey.p, w.cellBase.p, w.sortIdx.p);
 	hipLaunchKernelGGL(k_cell_rank, grid, block, 0, w.stream, w.dCounters.p, mask, w.hashKey.p, w.cellBase.p, w.cellCount.p, w.sortIdx.p, w.hashKeySorted.p, w.sortIdxSorted.p);
 	hipLaunchKernelGGL(k_gather_sorted, grid, block, 0, w.stream, mask, w.hashKeySorted.p, w.sortIdxSorted.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p,
-		w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p);
+		w.sBox.p, w.cellStart.p);
 	w.pairSlab.ensure((size_t)bound * PAIR_SLAB, w.stream);
 	if (w.lastError) return;
-	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_SLAB>), dim3((u32)(((size_t)bound * PAIR_LANES + 255) / 256)), block, 0, w.stream, bound, mask, w.sCellKey.p, w.sMin.p, w.sMax.p, w.cellStart.p, w.cellEnd.p, w.dCounters.p,
+	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_SLAB>), dim3((u32)(((size_t)bound * PAIR_LANES + 255) / 256)), block, 0, w.stream, bound, mask, w.sBox.p, (const uint2*)w.cellStart.p, w.dCounters.p,
 		w.pairCount.p, w.pairOffset.p, w.pairSlab.p, 0u);
 	prim_exclusive_scan_u32(w, w.pairCount.p, w.pairOffset.p, bound);
 	hipLaunchKernelGGL(k_finish_pair_count, dim3(1), dim3(64), 0, w.stream, bound, w.pairCount.p, w.pairOffset.p, w.dCounters.p, w.sapPartial.p, w.sapBlocks, w.stats.numInternalSteps & 1u);
@@ -295,6 +298,5 @@ void launch_broadphase_write(World& w, u32 numPairs, bool slabOverflow)
 	if (!nc || !numPairs) return;
 	hipLaunchKernelGGL(k_pairs_pack, dim3((u32)(((size_t)nc * PAIR_SLAB + 255) / 256)), dim3(256), 0, w.stream, nc, w.pairCount.p, w.pairOffset.p, w.pairSlab.p, w.pairs.p, (u32)w.pairCap);
 	if (slabOverflow) // some colliders have more than PAIR_SLAB partners: those (only) repeat their traversal, writing in place
-		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_WRITE>), dim3((u32)(((size_t)nc * PAIR_LANES + 255) / 256)), dim3(256), 0, w.stream, nc, w.hashTableSize - 1, w.sCellKey.p, w.sMin.p, w.sMax.p,
-			w.cellStart.p, w.cellEnd.p, w.dCounters.p, w.pairCount.p, w.pairOffset.p, w.pairs.p, (u32)w.pairCap);
+		hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_WRITE>), dim3((u32)(((size_t)nc * PAIR_LANES + 255) / 256)), dim3(256), 0, w.stream, nc, w.hashTableSize - 1, w.sBox.p, (const uint2*)w.cellStart.p, w.dCounters.p, w.pairCount.p, w.pairOffset.p, w.pairs.p, (u32)w.pairCap);
 }
