@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(256) k_gather_sorted(u32 hashMask, const u32* 
 	const u32 nc = counters[CTR_ACTIVE_COLS];
 	float cell = fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f) * 1.001f;
 	float invCell = 1.f / cell;
+	if (blockIdx.x == 0 && threadIdx.x == 0) counters[CTR_CELL_SIZE_USED] = counters[CTR_CELL_SIZE]; // for the pair kernels (the second one runs after the reset)
 	for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < nc; t += gridDim.x * blockDim.x)
 	{
 		u32 idx = idxSorted[t];
@@ -143,7 +144,7 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const float
 		else if (g == 14) { s = firstLarge; e = nEnd; }
 		else if (g < 14)
 		{
-			const float invCell = 1.f / (fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f) * 1.001f); // (as k_gather_sorted computes it)
+			const float invCell = 1.f / (fmaxf(__uint_as_float(counters[CTR_CELL_SIZE_USED]), 1e-3f) * 1.001f); // (as k_gather_sorted computes it)
 			i32 ix = cellCoord(amin.x, invCell), iy = cellCoord(amin.y, invCell), iz = cellCoord(amin.z, invCell);
 			i32 o = 13 + (i32)g; // offsets (dz,dy,dx) >= (0,0,0) in lexicographic order: own cell first, then the forward half
 			i32 dz = o / 9 - 1, dy = (o / 3) % 3 - 1, dx = o % 3 - 1;

@@ -762,6 +762,8 @@ struct EpaWave
 	u32 border[EPA_MAX_BORDER], newEdgePerPoint[EPA_MAX_POINTS];
 };
 #define EPA_NONE32 0xFFFFu
+#define EPA_GROUP 32u                 // lanes per polytope (>= EPA_MAX_BORDER and EPA_MAX_POINTS: one lane per border edge / point)
+#define EPA_GROUP_MASK 0xFFFFFFFFu
 #define WAVE_SYNC() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier()
 
 __device__ __forceinline__ V3 epaMk(const EpaWave& e, u32 i) { return v3(e.pa[i][0], e.pa[i][1], e.pa[i][2]) - v3(e.pb[i][0], e.pb[i][1], e.pb[i][2]); }
@@ -776,9 +778,13 @@ __device__ __forceinline__ void epaSetTri(EpaWave& e, u32 t, u32 a, u32 b, u32 c
 	e.ta[t] = a; e.tb[t] = b; e.tc[t] = c; e.teA[t] = eA; e.teB[t] = eB; e.teC[t] = eC; e.tactive[t] = 1;
 }
 
-// Runs on a full wave; every lane returns the same (point, normal, depth).
+// Runs on a GROUP of EPA_GROUP lanes (two polytopes per wave: the scalar part of an iteration — support point, termination test, the
+// bookkeeping — is issued once for both, and the kernel is bound by instruction issue); every lane of a group returns the same
+// (point, normal, depth).  `lane` is the lane inside the group.  Counts and indices are uniform inside a group, not across the wave:
+// the two groups' loops and exits diverge freely, every cross-lane operation (shuffles below EPA_GROUP, ballots cut to the group's
+// bits) stays inside a group, and WAVE_SYNC orders a group's LDS traffic whatever the other group is doing.
 template <int FAMILY>
-__device__ void epaWave(EpaWave& e, u32 lane, const GjkSimplex& g, const SupShapes& sh, V3& outPoint, V3& outNormal, float& outDepth)
+__device__ void epaWave(EpaWave& e, u32 lane, u32 groupShift, const GjkSimplex& g, const SupShapes& sh, V3& outPoint, V3& outNormal, float& outDepth)
 {
 	u32 numTris = 4, numPoints = 4, numEdges = 6;
 	if (lane == 0)
@@ -798,8 +804,8 @@ __device__ void epaWave(EpaWave& e, u32 lane, const GjkSimplex& g, const SupShap
 	{
 		// findTriangleClosestToOrigin (collision_epa.cpp:89-109): lowest index among the minimal distances
 		float bd = MI_FLT_MAX; u32 bi = 0xFFFFFFFFu;
-		for (u32 t = lane; t < numTris; t += 64) { if (e.tactive[t]) { float d = e.tdist[t]; if (d < bd) { bd = d; bi = t; } } }
-		for (int o = 32; o > 0; o >>= 1)
+		for (u32 t = lane; t < numTris; t += EPA_GROUP) { if (e.tactive[t]) { float d = e.tdist[t]; if (d < bd) { bd = d; bi = t; } } }
+		for (int o = EPA_GROUP / 2; o > 0; o >>= 1)
 		{
 			float od = __shfl_xor(bd, o); u32 oi = __shfl_xor(bi, o);
 			if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
@@ -812,10 +818,10 @@ __device__ void epaWave(EpaWave& e, u32 lane, const GjkSimplex& g, const SupShap
 		if (dd - e.tdist[closest] < 0.01f) break;
 
 		// addNewPointAndUpdate (collision_epa.cpp:111-239)
-		for (u32 i = lane; i < numEdges; i += 64) e.refs[i] = 0;
+		for (u32 i = lane; i < numEdges; i += EPA_GROUP) e.refs[i] = 0;
 		if (lane < EPA_MAX_POINTS) e.newEdgePerPoint[lane] = 0;
 		WAVE_SYNC();
-		for (u32 t = lane; t < numTris; t += 64)
+		for (u32 t = lane; t < numTris; t += EPA_GROUP)
 		{
 			if (e.tactive[t])
 			{
@@ -825,14 +831,14 @@ __device__ void epaWave(EpaWave& e, u32 lane, const GjkSimplex& g, const SupShap
 		}
 		WAVE_SYNC();
 		u32 nBorder = 0;
-		for (u32 base = 0; base < numEdges; base += 64) // border edges in edge-index order
+		for (u32 base = 0; base < numEdges; base += EPA_GROUP) // border edges in edge-index order
 		{
 			u32 i = base + lane;
 			bool flag = i < numEdges && e.refs[i] == 1;
-			u64 mask = __ballot(flag);
-			u32 pos = nBorder + __popcll(mask & ((1ull << lane) - 1ull));
+			u32 mask = (u32)(__ballot(flag) >> groupShift) & EPA_GROUP_MASK; // (the other group's lanes, if they are in this loop at all, vote in their own bits)
+			u32 pos = nBorder + __popc(mask & ((1u << lane) - 1u));
 			if (flag && pos < EPA_MAX_BORDER) e.border[pos] = i;
-			nBorder += __popcll(mask);
+			nBorder += __popc(mask);
 		}
 		if (nBorder > EPA_MAX_BORDER) break;                                     // "out of memory" exits, as the serial code's pushes would hit them
 		if (numPoints >= EPA_MAX_POINTS) break;
@@ -1052,19 +1058,21 @@ __global__ void __launch_bounds__(256) k_gjk(u32* __restrict__ counters, const u
 	for (u32 i = 0; i < 9; ++i) S[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
 }
 
-// Phase 2: EPA (one wave per hit, polytope in LDS) + face clipping (lane 0) for every GJK hit.  Waves stride over the work list.
+// Phase 2: EPA (EPA_GROUP lanes per hit = two hits per wave, polytopes in LDS) + face clipping (the group's first lane) for every GJK
+// hit.  Groups stride over the work list.
 #define EPA_WAVES_PER_BLOCK 4
+#define EPA_PER_WAVE (64 / EPA_GROUP)
 template <int FAMILY>
-__global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(FAMILY == 0 ? 4 : 2, FAMILY == 0 ? 4 : 3))) k_epa(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
+__global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) __attribute__((amdgpu_waves_per_eu(FAMILY == 0 ? 3 : 2, FAMILY == 0 ? 3 : 3))) k_epa(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
 	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds, const u32* __restrict__ epaList, const float4* __restrict__ gjkSimplex,
 	const float4* __restrict__ hullInfo, const float4* __restrict__ hullVerts, u32 listCap)
 {
-	__shared__ EpaWave shared[EPA_WAVES_PER_BLOCK];
-	u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	EpaWave& e = shared[wave];
+	__shared__ EpaWave shared[EPA_WAVES_PER_BLOCK * EPA_PER_WAVE];
+	const u32 wave = threadIdx.x >> 6, group = (threadIdx.x & 63u) / EPA_GROUP, lane = threadIdx.x & (EPA_GROUP - 1u);
+	EpaWave& e = shared[wave * EPA_PER_WAVE + group];
 	u32 numHits = counters[FAMILY == 0 ? CTR_EPA_COUNT : CTR_EPA_COUNT_HULL];
-	u32 stride = gridDim.x * EPA_WAVES_PER_BLOCK;
-	for (u32 jj = blockIdx.x * EPA_WAVES_PER_BLOCK + wave; jj < numHits; jj += stride)
+	u32 stride = gridDim.x * EPA_WAVES_PER_BLOCK * EPA_PER_WAVE;
+	for (u32 jj = (blockIdx.x * EPA_WAVES_PER_BLOCK + wave) * EPA_PER_WAVE + group; jj < numHits; jj += stride)
 	{
 		u32 j = (FAMILY == 0) ? jj : listCap - 1u - jj;
 		u32 slot = epaList[j];
@@ -1080,7 +1088,7 @@ __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) __attribute__((amdgp
 		SupportPoint* P[4] = { &sx.a, &sx.b, &sx.c, &sx.d };
 		for (u32 i = 0; i < 4; ++i) { P[i]->a = v3(f[9 * i], f[9 * i + 1], f[9 * i + 2]); P[i]->b = v3(f[9 * i + 3], f[9 * i + 4], f[9 * i + 5]); P[i]->mk = v3(f[9 * i + 6], f[9 * i + 7], f[9 * i + 8]); }
 		V3 point, normal; float depth;
-		epaWave<FAMILY>(e, lane, sx, sh, point, normal, depth);
+		epaWave<FAMILY>(e, lane, group * EPA_GROUP, sx, sh, point, normal, depth);
 		if (lane == 0)
 		{
 			Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);

@@ -97,6 +97,7 @@ enum
 	CTR_ACTIVE_BODIES = 377, // simulated bodies / their colliders + the static ones (lengths of the active lists, k_active_scan); more of the latter than the broadphase was launched for
 	CTR_ACTIVE_COLS = 378,
 	CTR_ACTIVE_OVERFLOW = 379,
+	CTR_CELL_SIZE_USED = 380, // float bits: the cell size the current sorted order was built with (CTR_CELL_SIZE is reset for the next step's atomicMax before the last pair kernel runs)
 	CTR_CL_SCRATCH = 371,   // cluster sweep: append cursor of the global row scratch (contacts that fit neither registers nor LDS), reset before every launch
 	CTR_VALIDATE = 448,     // 2 words: non-finite values found by the debug guard (MI_PHYSICS_VALIDATE=1), first offender (stage << 28 | index)
 	CTR_CL_REMAIN = 442,    // 6 words: manifolds still unassigned when partition phase p starts ([0] unused: all active ones)
