@@ -140,10 +140,26 @@ MI_DEV u32 clPhaseOffset(const u32* counters, u32 p)
 }
 // A phase may not have more tasks than the solve launch has workgroups (task t of a phase runs on workgroup (offset + t) % G, all
 // of them resident): when the pile outgrows "G tasks of the configured weight", the chunks grow instead.  cum[nb] = total weight.
-MI_DEV u32 clEffectiveWeight(u32 taskWeight, u32 totalWeight, u32 maxTasks)
+// And a world of jointed islands that would leave most workgroups without a first-phase task — 256 ragdolls — is spread over the
+// launch in smaller tasks (fewer joints and colours per task; islands are never cut, so smaller tasks cost no extra hand-overs;
+// config 4: 28 -> 165 tasks, 0.583 ms at 1000, 0.544 at 400, 0.516 at 150, 0.522 at 100), down to CL_WEIGHT_SPREAD_MIN.  Only the first
+// phase (its weight argument carries CL_WEIGHT_ISLANDS).  Contact-only worlds keep their chunks: smaller ones cut more manifolds
+// (config 2, 10 k spheres: no gain at 300, a fourth phase at 150).
+#define CL_WEIGHT_ISLANDS 0x80000000u
+#define CL_WEIGHT_SPREAD_MIN (64u * 150u)
+MI_DEV u32 clEffectiveWeight(u32 taskWeightArg, u32 totalWeight, u32 maxTasks)
 {
+	const u32 taskWeight = taskWeightArg & ~CL_WEIGHT_ISLANDS;
 	u32 need = totalWeight / maxTasks + 1u;                                   // one task per workgroup ...
-	if (need <= taskWeight) return taskWeight;
+	if (need <= taskWeight)
+	{
+		if ((taskWeightArg & CL_WEIGHT_ISLANDS) && 2u * need <= taskWeight)
+		{
+			const u32 spread = need + need / 2u;
+			return spread > CL_WEIGHT_SPREAD_MIN ? spread : min(CL_WEIGHT_SPREAD_MIN, taskWeight);
+		}
+		return taskWeight;
+	}
 	if (need <= CL_WEIGHT_REG_LIMIT) return need;                             // ... as long as such a task still fits the lanes' registers,
 	u32 need2 = totalWeight / (CL_TASKS_PER_PHASE * maxTasks) + 1u;             // then up to CL_TASKS_PER_PHASE per workgroup (the later ones run from LDS)
 	return need2 > CL_WEIGHT_REG_LIMIT ? need2 : CL_WEIGHT_REG_LIMIT;
@@ -1447,6 +1463,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 	if (w.lastError) return;
 	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.clJointCount.p, w.dCounters.p, w.clCompLabel.p);
 	u32* leftList = w.useComponents ? w.clLeftList.p : nullptr; const u32 leftCap = (u32)w.pairCap;
+	const u32 firstFlags = withJoints ? CL_WEIGHT_ISLANDS : 0u; // (goes with the first phase's weight)
 	const u32 maxTasks = std::min<u32>(CL_MAX_TASKS / CL_TASKS_PER_PHASE, w.clusterBlocks) - std::min<u32>(8u, w.clusterBlocks / 8u); // per phase, with a margin for the chunks' rounding
 	w.clChunk.ensure((size_t)CL_MAX_PARTS * nb1, w.stream);
 	if (w.lastError) return;
@@ -1461,12 +1478,12 @@ void launch_cluster_build(World& w, u32 numPairs)
 		{
 			u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
 			prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
-			hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, p ? weightLater : weight0, maxTasks, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
+			hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, p ? weightLater : (weight0 | firstFlags), maxTasks, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
 				w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, p == 0 ? rep : nullptr, leftList, leftCap);
 			if (p == 0 && nj) // (cum still holds phase 0's scan)
-				hipLaunchKernelGGL(k_cl_joint_assign, dim3((nj + 255) / 256), block, 0, w.stream, nj, nb, weight0, maxTasks, w.clJointTable.p, w.clRank.p, rep, w.clCum.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
+				hipLaunchKernelGGL(k_cl_joint_assign, dim3((nj + 255) / 256), block, 0, w.stream, nj, nb, weight0 | firstFlags, maxTasks, w.clJointTable.p, w.clRank.p, rep, w.clCum.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS);
 			if (w.useChunkCache)
-				hipLaunchKernelGGL(k_cl_store_chunks, bgrid, block, 0, w.stream, nb, p ? weightLater : weight0, maxTasks, w.clRank.p + (size_t)p * nb1, w.clCum.p, p == 0 ? rep : nullptr, w.clChunk.p + (size_t)p * nb1);
+				hipLaunchKernelGGL(k_cl_store_chunks, bgrid, block, 0, w.stream, nb, p ? weightLater : (weight0 | firstFlags), maxTasks, w.clRank.p + (size_t)p * nb1, w.clCum.p, p == 0 ? rep : nullptr, w.clChunk.p + (size_t)p * nb1);
 		}
 		w.clChunkParts = parts; w.clChunkJointVersion = w.jointVersion; w.clChunkWithJoints = withJoints;
 	}
@@ -1480,7 +1497,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 		{
 			u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
 			prim_exclusive_scan_u32(w, wsum, w.clCum.p, nb + 1);
-			hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, p ? w.clusterTaskWeightLater : w.clusterTaskWeight, maxTasks, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
+			hipLaunchKernelGGL(k_cl_assign, mgrid, block, 0, w.stream, w.dCounters.p, nb, p, parts, p ? w.clusterTaskWeightLater : (w.clusterTaskWeight | firstFlags), maxTasks, w.actIds.p, w.clRank.p + (size_t)p * nb1, w.clCum.p,
 				w.clRank.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1, wsumNext, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, w.dCounters.p + CTR_CL_STATUS, (const u32*)nullptr, leftList, leftCap);
 		}
 	}
