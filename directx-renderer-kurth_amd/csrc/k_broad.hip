@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_cell_assign(const u32* __restrict__ act
 	u32* __restrict__ counters, u32* __restrict__ hashKey, u32* __restrict__ cellCount)
 {
 	const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
-	if (gid == 0) { counters[CTR_FIRST_LARGE] = 0xFFFFFFFFu; counters[CTR_FIRST_INACTIVE] = 0xFFFFFFFFu; counters[CTR_PAIR_OVERFLOW] = 0u; } // "none" until k_gather_sorted / k_pairs say otherwise
+	if (gid == 0) { counters[CTR_FIRST_LARGE] = 0xFFFFFFFFu; counters[CTR_FIRST_INACTIVE] = 0xFFFFFFFFu; counters[CTR_PAIR_OVERFLOW] = 0u; } // "none" until k_cell_rank / k_pairs say otherwise
 	const u32 n = counters[CTR_ACTIVE_COLS];
 	float maxExtent = fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f);
 	float cell = maxExtent * 1.001f;
@@ -69,43 +69,30 @@ __global__ void __launch_bounds__(256) k_cell_place(const u32* __restrict__ coun
 	const u32 n = counters[CTR_ACTIVE_COLS];
 	for (u32 a = blockIdx.x * blockDim.x + threadIdx.x; a < n; a += gridDim.x * blockDim.x) { const u32 i = activeCols[a]; tmpIdx[atomicAdd(&cellBase[hashKey[i]], 1u)] = i; }
 }
-__global__ void __launch_bounds__(256) k_cell_rank(const u32* __restrict__ counters, u32 hashMask, const u32* __restrict__ hashKey, const u32* __restrict__ cellBase, const u32* __restrict__ cellCount, const u32* __restrict__ tmpIdx,
-	u32* __restrict__ hashSorted, u32* __restrict__ idxSorted)
+// ... and, knowing its position, writes the collider's sorted record there and, as the first of its bucket, the bucket's range
+// (what a separate gather pass over the sorted indices did before: one launch and two index arrays fewer).
+__global__ void __launch_bounds__(256) k_cell_rank(u32* __restrict__ counters, u32 hashMask, const u32* __restrict__ hashKey, const u32* __restrict__ cellBase, const u32* __restrict__ cellCount, const u32* __restrict__ tmpIdx,
+	const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax, float4* __restrict__ sBox, u32* __restrict__ cellRange)
 {
 	const u32 n = counters[CTR_ACTIVE_COLS];
+	const float cell = fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f) * 1.001f;
+	const float invCell = 1.f / cell;
+	if (blockIdx.x == 0 && threadIdx.x == 0) counters[CTR_CELL_SIZE_USED] = counters[CTR_CELL_SIZE]; // for the pair kernels (the second one runs after the reset)
 	for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
 	{
 		const u32 i = tmpIdx[t], h = hashKey[i], end = cellBase[h], start = end - cellCount[h];
 		u32 rank = t - start;
 		if (h != hashMask + 2u) { rank = 0; for (u32 u = start; u < end; ++u) rank += tmpIdx[u] < i ? 1u : 0u; }
-		hashSorted[start + rank] = h; idxSorted[start + rank] = i;
-	}
-}
-
-__global__ void __launch_bounds__(256) k_gather_sorted(u32 hashMask, const u32* __restrict__ hashSorted, const u32* __restrict__ idxSorted,
-	const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax, u32* __restrict__ counters,
-	float4* __restrict__ sBox, u32* __restrict__ cellRange)
-{
-	const u32 nc = counters[CTR_ACTIVE_COLS];
-	float cell = fmaxf(__uint_as_float(counters[CTR_CELL_SIZE]), 1e-3f) * 1.001f;
-	float invCell = 1.f / cell;
-	if (blockIdx.x == 0 && threadIdx.x == 0) counters[CTR_CELL_SIZE_USED] = counters[CTR_CELL_SIZE]; // for the pair kernels (the second one runs after the reset)
-	for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < nc; t += gridDim.x * blockDim.x)
-	{
-		u32 idx = idxSorted[t];
-		u32 h = hashSorted[t];
-		float4 mn = aabbMin[idx], mx = aabbMax[idx];
+		const u32 pos = start + rank;
+		float4 mn = aabbMin[i], mx = aabbMax[i];
 		mx.w = __uint_as_float(cellTag(cellCoord(mn.x, invCell), cellCoord(mn.y, invCell), cellCoord(mn.z, invCell)));
-		mn.w = __uint_as_float(idx);
-		sBox[2 * t] = mn; sBox[2 * t + 1] = mx; // one 32-byte record per sorted position: a candidate test is ONE cache line (three arrays were three)
-		u32 hPrev = (t > 0) ? hashSorted[t - 1] : 0xFFFFFFFFu;
-		u32 hNext = (t + 1 < nc) ? hashSorted[t + 1] : 0xFFFFFFFFu;
-		if (h <= hashMask)
+		mn.w = __uint_as_float(i);
+		sBox[2 * pos] = mn; sBox[2 * pos + 1] = mx; // one 32-byte record per sorted position: a candidate test is ONE cache line (three arrays were three)
+		if (t == start) // (one thread per non-empty bucket)
 		{
-			if (hPrev != h) cellRange[2 * h] = t;
-			if (hNext != h) cellRange[2 * h + 1] = t + 1;
+			if (h <= hashMask) { cellRange[2 * h] = start; cellRange[2 * h + 1] = end; }
+			else counters[h == hashMask + 1 ? CTR_FIRST_LARGE : CTR_FIRST_INACTIVE] = start;
 		}
-		else if (hPrev != h) { counters[h == hashMask + 1 ? CTR_FIRST_LARGE : CTR_FIRST_INACTIVE] = t; }
 	}
 }
 
@@ -144,7 +131,7 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const float
 		else if (g == 14) { s = firstLarge; e = nEnd; }
 		else if (g < 14)
 		{
-			const float invCell = 1.f / (fmaxf(__uint_as_float(counters[CTR_CELL_SIZE_USED]), 1e-3f) * 1.001f); // (as k_gather_sorted computes it)
+			const float invCell = 1.f / (fmaxf(__uint_as_float(counters[CTR_CELL_SIZE_USED]), 1e-3f) * 1.001f); // (as k_cell_rank computes it)
 			i32 ix = cellCoord(amin.x, invCell), iy = cellCoord(amin.y, invCell), iz = cellCoord(amin.z, invCell);
 			i32 o = 13 + (i32)g; // offsets (dz,dy,dx) >= (0,0,0) in lexicographic order: own cell first, then the forward half
 			i32 dz = o / 9 - 1, dy = (o / 3) % 3 - 1, dx = o % 3 - 1;
@@ -282,9 +269,7 @@ void launch_broadphase_count(World& w)
 	hipLaunchKernelGGL(k_cell_assign, grid, block, 0, w.stream, w.actCols.p, mask, w.aabbMin.p, w.aabbMax.p, w.dCounters.p, w.hashKey.p, w.cellCount.p);
 	prim_exclusive_scan_u32(w, w.cellCount.p, w.cellBase.p, H + 3);
 	hipLaunchKernelGGL(k_cell_place, grid, block, 0, w.stream, w.dCounters.p, w.actCols.p, w.hashKey.p, w.cellBase.p, w.sortIdx.p);
-	hipLaunchKernelGGL(k_cell_rank, grid, block, 0, w.stream, w.dCounters.p, mask, w.hashKey.p, w.cellBase.p, w.cellCount.p, w.sortIdx.p, w.hashKeySorted.p, w.sortIdxSorted.p);
-	hipLaunchKernelGGL(k_gather_sorted, grid, block, 0, w.stream, mask, w.hashKeySorted.p, w.sortIdxSorted.p, w.aabbMin.p, w.aabbMax.p, w.dCounters.p,
-		w.sBox.p, w.cellStart.p);
+	hipLaunchKernelGGL(k_cell_rank, grid, block, 0, w.stream, w.dCounters.p, mask, w.hashKey.p, w.cellBase.p, w.cellCount.p, w.sortIdx.p, w.aabbMin.p, w.aabbMax.p, w.sBox.p, w.cellStart.p);
 	w.pairSlab.ensure((size_t)bound * PAIR_SLAB, w.stream);
 	if (w.lastError) return;
 	hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pairs<MODE_SLAB>), dim3((u32)(((size_t)bound * PAIR_LANES + 255) / 256)), block, 0, w.stream, bound, mask, w.sBox.p, (const uint2*)w.cellStart.p, w.dCounters.p,

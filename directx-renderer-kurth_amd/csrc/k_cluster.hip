@@ -491,24 +491,37 @@ __global__ void __launch_bounds__(256) k_cl_comp_assign(u32* __restrict__ counte
 #undef CL_LD
 
 // One workgroup: exclusive scan of the per-task counts -> first slot of every task; tasks per phase; end of schedule.
+// Inclusive prefix sum over the 1024 lanes of a workgroup: shuffles inside a wave, one LDS step across the 16 waves (two barriers; a
+// Hillis-Steele ladder through LDS was 20).
+MI_DEV u32 clBlockInclusive1024(u32 v, u32* waveTotals /* [16], LDS */)
+{
+	const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	for (u32 o = 1; o < 64u; o <<= 1) { u32 up = __shfl_up(v, o); if (lane >= o) v += up; }
+	if (lane == 63u) waveTotals[wave] = v;
+	__syncthreads();
+	u32 before = 0;
+	for (u32 k = 0; k < 16u; ++k) before += (k < wave) ? waveTotals[k] : 0u;
+	__syncthreads(); // (waveTotals is reused by the next call)
+	return v + before;
+}
 __global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters, u32 numParts, const u32* __restrict__ taskCount, u32* __restrict__ taskStart, const u32* __restrict__ jointCount, u32* __restrict__ jointStart)
 {
-	__shared__ u32 part[1024];
+	__shared__ u32 part[16];
 	__shared__ u32 lastTask[CL_MAX_PHASES];
 	const u32 total = CL_MAX_PHASES * CL_MAX_TASKS * CL_SUBCOUNTERS, per = (total + 1023u) / 1024u;
 	u32 t = threadIdx.x;
 	if (t < CL_MAX_PHASES) lastTask[t] = 0;
+	__shared__ uint16_t cnt[CL_MAX_PHASES * CL_MAX_TASKS * CL_SUBCOUNTERS]; // the counters, read once with neighbouring lanes on neighbouring words (a sub-counter holds < 64 k)
+	for (u32 e = t; e < total; e += 1024u) cnt[e] = (uint16_t)min(taskCount[e], 0xFFFFu);
+	__syncthreads(); // (cnt, lastTask)
 	u32 sum = 0;
-	for (u32 k = 0; k < per; ++k) if (t * per + k < total) sum += taskCount[t * per + k];
-	part[t] = sum;
-	__syncthreads();
-	for (u32 o = 1; o < 1024u; o <<= 1) { u32 v = (t >= o) ? part[t - o] : 0u; __syncthreads(); part[t] += v; __syncthreads(); }
-	u32 run = part[t] - sum;
+	for (u32 k = 0; k < per; ++k) if (t * per + k < total) sum += cnt[t * per + k];
+	u32 run = clBlockInclusive1024(sum, part) - sum;
 	for (u32 k = 0; k < per; ++k)
 	{
 		u32 e = t * per + k;
 		if (e >= total) break;
-		u32 c = taskCount[e], key = e / CL_SUBCOUNTERS;
+		u32 c = cnt[e], key = e / CL_SUBCOUNTERS;
 		taskStart[e] = run; run += c;
 		if (c) atomicMax(&lastTask[key / CL_MAX_TASKS], (key % CL_MAX_TASKS) + 1u);
 	}
@@ -517,10 +530,8 @@ __global__ void __launch_bounds__(1024) k_cl_offsets(u32* __restrict__ counters,
 	// joints per phase-0 task (CL_MAX_TASKS <= 1024 entries: one per lane); a task may hold joints and no manifold
 	{
 		u32 jc = (jointCount && t < CL_MAX_TASKS) ? jointCount[t] : 0u;
-		part[t] = jc;
-		__syncthreads();
-		for (u32 o = 1; o < 1024u; o <<= 1) { u32 v = (t >= o) ? part[t - o] : 0u; __syncthreads(); part[t] += v; __syncthreads(); }
-		if (jointStart && t < CL_MAX_TASKS) { jointStart[t] = part[t] - jc; if (t == CL_MAX_TASKS - 1u) jointStart[CL_MAX_TASKS] = part[t]; }
+		const u32 jIncl = jointCount ? clBlockInclusive1024(jc, part) : 0u; // (uniform branch)
+		if (jointStart && t < CL_MAX_TASKS) { jointStart[t] = jIncl - jc; if (t == CL_MAX_TASKS - 1u) jointStart[CL_MAX_TASKS] = jIncl; }
 		if (jc) atomicMax(&lastTask[0], t + 1u);
 		__syncthreads();
 	}

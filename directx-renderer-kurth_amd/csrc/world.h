@@ -171,7 +171,7 @@ struct World
 	DevBuf<uint8_t> slabCode; DevBuf<u32> slabFresh; u32 slabRank = 0, slabSize = 0, slabAxis = 0, slabStamp = 0; float slabLo = 0.f, slabHi = 0.f, slabMargin = 0.f;
 	// broadphase
 	DevBuf<u32> cellCount, cellBase;      // colliders per cell bucket (+ 'large', 'simulated elsewhere'), first / end position of every bucket in the sorted order
-	DevBuf<u32> hashKey, hashKeySorted, sortIdx, sortIdxSorted, cellStart /* {first, end} per bucket */, largeFlag, largeScan, largeList, pairCount, pairOffset;
+	DevBuf<u32> hashKey, sortIdx, cellStart /* {first, end} per bucket */, largeFlag, largeScan, largeList, pairCount, pairOffset;
 	DevBuf<float4> sBox; // sorted colliders: {min.xyz, collider index} {max.xyz, cell tag} per position
 	// active lists (k_bodies.hip): the simulated bodies, their colliders + the static ones, ascending; rebuilt when the simulate mask may have changed
 	DevBuf<u32> actBodies, actCols, actBlockCount, actBlockBase, colBody; bool activeDirty = true; u32 estActiveBodies = 0, estActiveCols = 0, pairBound = 0, sapBlocks = 0;

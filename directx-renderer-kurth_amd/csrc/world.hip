@@ -86,7 +86,7 @@ World::~World()
 	if (stream) (void)hipStreamSynchronize(stream);
 	DevBuf<float4>* f4[] = { &pose, &pose0, &poseLerp, &vel, &bprops, &force, &cog, &invIw, &colStaticPose, &aabbMin, &aabbMax, &sBox, &rowPlanes, &rowShared };
 	for (auto b : f4) b->release();
-	DevBuf<u32>* u4[] = { &hashKey, &hashKeySorted, &sortIdx, &sortIdxSorted, &cellStart, &largeFlag, &largeScan, &largeList, &pairCount, &pairOffset, &pairKey, &pairKeySorted,
+	DevBuf<u32>* u4[] = { &hashKey, &sortIdx, &cellStart, &largeFlag, &largeScan, &largeList, &pairCount, &pairOffset, &pairKey, &pairKeySorted,
 		&mColor, &mKey, &mKeySorted, &mIdx, &mOrder, &dCounters };
 	for (auto b : u4) b->release();
 	colLocal.release(); colWorld.release(); pairs.release(); pairsSorted.release(); manifolds.release(); bodyMask.release(); claim.release();
@@ -360,7 +360,7 @@ void World::upload()
 	fieldsDirty = true; // (re)sizes the per-body field bits
 	size_t ncap = std::max<size_t>(nc, 1);
 	colLocal.ensure(ncap, stream); colWorld.ensure(ncap, stream); colStaticPose.ensure(2 * ncap, stream); aabbMin.ensure(ncap, stream); aabbMax.ensure(ncap, stream);
-	hashKey.ensure(ncap, stream); hashKeySorted.ensure(ncap, stream); sortIdx.ensure(ncap, stream); sortIdxSorted.ensure(ncap, stream);
+	hashKey.ensure(ncap, stream); sortIdx.ensure(ncap, stream);
 	sBox.ensure(2 * ncap, stream); pairCount.ensure(ncap + 1, stream); pairOffset.ensure(ncap + 1, stream);
 	hashTableSize = std::max(1024u, nextPow2(2 * nc));
 	cellStart.ensure(2 * (size_t)hashTableSize, stream); cellCount.ensure(hashTableSize + 4, stream); cellBase.ensure(hashTableSize + 4, stream);
