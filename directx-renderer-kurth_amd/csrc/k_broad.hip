@@ -148,15 +148,24 @@ __global__ void __launch_bounds__(256) k_pairs(u32 nc, u32 hashMask, const float
 	}
 	u32 n = 0;
 	u32 hit0 = 0, hit1 = 0, hit2 = 0, hit3 = 0; // the first four partners of this lane stay in registers: the write pass then needs no second visit
-	for (u32 u = s; u < e; ++u)
+	// (four candidates per turn, their boxes requested together — eight cost more in registers than they save: a wave's time is the longest lane's chain of dependent loads —
+	// 78 load instructions per wave, 82 % of its cycles parked on them, when every candidate waited for the one before it)
+	for (u32 u = s; u < e; u += 4u)
 	{
-		float4 bmin = sBox[2 * u], bmax = sBox[2 * u + 1];
-		if (checkKey && __float_as_uint(bmax.w) != ntag) continue;
-		if (aabbOverlap(amin, amax, bmin, bmax))
+		float4 bmin[4], bmax[4];
+#pragma unroll
+		for (u32 k = 0; k < 4u; ++k) if (u + k < e) { bmin[k] = sBox[2 * (u + k)]; bmax[k] = sBox[2 * (u + k) + 1]; }
+#pragma unroll
+		for (u32 k = 0; k < 4u; ++k)
 		{
-			u32 partner = __float_as_uint(bmin.w);
-			if (n == 0) hit0 = partner; else if (n == 1) hit1 = partner; else if (n == 2) hit2 = partner; else if (n == 3) hit3 = partner;
-			++n;
+			if (u + k >= e) continue;
+			if (checkKey && __float_as_uint(bmax[k].w) != ntag) continue;
+			if (aabbOverlap(amin, amax, bmin[k], bmax[k]))
+			{
+				u32 partner = __float_as_uint(bmin[k].w);
+				if (n == 0) hit0 = partner; else if (n == 1) hit1 = partner; else if (n == 2) hit2 = partner; else if (n == 3) hit3 = partner;
+				++n;
+			}
 		}
 	}
 	// exclusive prefix over the 16 lanes of the group (the groups of a wave are aligned to 16 lanes)

@@ -347,14 +347,19 @@ __global__ void __launch_bounds__(256) k_cl_assign_cached(u32* counters, u32 nb,
 		ids = actIds[j];
 		da = ids.x < nb; db = ids.y < nb;
 		if (!dumpAll)
+		{
+			// (the first two phases' chunks are requested together: a manifold the first phase cuts does not wait a second round trip)
+			const u32* c1 = chunk + (size_t)(nb + 1u);
+			u32 ta = da ? chunk[ids.x] : 0u, tb = db ? chunk[ids.y] : 0u, ta1 = (da && numCached > 1u) ? c1[ids.x] : 0u, tb1 = (db && numCached > 1u) ? c1[ids.y] : 0u;
 			for (u32 p = 0; p < numCached; ++p)
 			{
-				const u32* c = chunk + (size_t)p * (nb + 1u);
-				u32 ta = da ? c[ids.x] : 0u, tb = db ? c[ids.y] : 0u;
+				if (p == 1u) { ta = ta1; tb = tb1; }
+				else if (p > 1u) { const u32* c = chunk + (size_t)p * (nb + 1u); ta = da ? c[ids.x] : 0u; tb = db ? c[ids.y] : 0u; }
 				if (!da) ta = tb;
 				if (!db) tb = ta;
 				if (ta == tb) { key = p * CL_MAX_TASKS + ta; phase = p; break; }
 			}
+		}
 	}
 	// manifolds still unassigned when phase q + 1 starts (statistics; the host adapts the number of phases from them)
 	const bool goesOn = live && phase == numParts && numCached < numParts && !dumpAll; // left by the cached phases, with a pipeline phase to go to
@@ -401,8 +406,8 @@ __global__ void __launch_bounds__(256) k_cl_assign_cached(u32* counters, u32 nb,
 		taskPos[j] = base + (u32)__popcll(mine & ((1ull << lane) - 1ull));
 	}
 	const u32 ph = key / CL_MAX_TASKS;
-	if (da && !(__hip_atomic_load(&phaseMask[ids.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << ph))) atomicOr(&phaseMask[ids.x], 1u << ph);
-	if (db && !(__hip_atomic_load(&phaseMask[ids.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (1u << ph))) atomicOr(&phaseMask[ids.y], 1u << ph);
+	if (da) atomicOr(&phaseMask[ids.x], 1u << ph); // (results unused: the wave does not wait for them; a load-then-or would)
+	if (db) atomicOr(&phaseMask[ids.y], 1u << ph);
 }
 __global__ void __launch_bounds__(256) k_cl_joint_assign_cached(u32 numJoints, const uint4* __restrict__ table, const u32* __restrict__ chunk0, u32* __restrict__ jointTask, u32* __restrict__ jointPos,
 	u32* __restrict__ jointCount, u32* __restrict__ phaseMask)
