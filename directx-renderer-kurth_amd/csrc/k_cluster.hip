@@ -36,7 +36,8 @@ void prim_exclusive_scan_u32(World& w, const u32* in, u32* out, u32 n);
 #define CL_MAX_LOCAL_TASKS 8u              // tasks of all phases per workgroup
 #define CLS_LANES 512u                    // k_cl_solve: 8 waves = 128 quads (four lanes work on one contact row) ...
 #define CLQ_QUADS (CLS_LANES / 4u)
-#define CLQ_SETS 8u                       // ... each keeping this many contact rows in registers (19 VGPRs per row and lane; 256 VGPRs per lane at 2 waves per SIMD)
+#define CLQ_SETS 7u                       // ... each keeping this many contact rows in registers (19 VGPRs per row and lane).  Eight sets reach the 256 VGPRs a launch of
+                                          // 2 waves per SIMD allows only with 12-21 registers spilled into the colour loop: 7 sets (236 VGPRs, none spilled) solve 8 % faster
 #define CLQ_REG_CONTACTS (CLQ_QUADS * CLQ_SETS) // contacts of a workgroup's first task that live in registers (worlds whose joints run inside the sweep: CLQ_SETS_JOINTS sets, the joint solves need the registers)
 #define CLQ_SETS_JOINTS 4u
 #define CL_WEIGHT_REG_LIMIT (64u * 1250u)  // chunk weight up to which a task's INTERIOR contacts (70 - 85 % of what its bodies own) fit the register sets, give or take what LDS holds
@@ -1208,7 +1209,7 @@ template <bool JOINTS> __global__ void __launch_bounds__(CLS_LANES) k_cl_solve(C
 		if (end > ((S_) + 1u) * CLQ_QUADS) { CLQ_SOLVE_SET((S_) + 1u, csCur, endReg) if (end > regC) { CLQ_SOLVE_ROWS(csCur, end) } } \
 		CLQ_ADVANCE(end) \
 	}
-	static_assert(CLQ_SETS == 8u, "the colour loop below names eight sets");
+	static_assert(CLQ_SETS <= 8u, "the colour loop below names eight sets");
 
 	// ---- iterations ----
 	bool aborted = false;
