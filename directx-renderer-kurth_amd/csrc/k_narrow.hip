@@ -315,7 +315,13 @@ MI_DEV bool boxBoxAxisAligned(Box a, Box b, Man& m) // :1074-1140
 // ---------------------------------------------------------------------------------------------------------------
 // Manifold helpers — collision_narrow.cpp:56-369.  Polygon vertices are float4 (xyz, penetrationDepth).
 // ---------------------------------------------------------------------------------------------------------------
-struct Poly { float4 pts[16]; u32 n; };
+// A clipping polygon: up to 16 points (x, y, z, penetration) — collision_narrow.cpp:148-152 — kept OUTSIDE the registers (its points are
+// indexed by loop counters): vertex i lives at pts[i * stride].  The box-box kernel gives every lane a column of an LDS array
+// (stride 64: a lane's accesses are LDS round trips, not scratch-memory ones through the vector memory path — its waves spent
+// 61 % of their cycles waiting for those); the lone lane that clips a capsule's segment behind EPA keeps a private array (stride 1).
+struct Poly { float4* pts; u32 stride; u32 n; };
+#define PP(P_, I_) (P_).pts[(I_) * (P_).stride]
+struct PolyStore { float4* a; float4* b; u32 stride; };
 
 MI_DEV float4 clipAgainstPlane(float4 a, float4 b, float aDist, float bDist) // :154-163
 {
@@ -332,19 +338,19 @@ MI_DEV void sutherlandHodgman(Poly& input, const float4* clipPlanes, u32 numClip
 		float4 plane = clipPlanes[clipIndex];
 		out->n = 0;
 		if (in->n == 0) break;
-		float4 startPoint = in->pts[in->n - 1];
+		float4 startPoint = PP(*in, in->n - 1);
 		for (u32 i = 0; i < in->n; ++i)
 		{
-			float4 endPoint = in->pts[i];
+			float4 endPoint = PP(*in, i);
 			float startDist = signedDistanceToPlane(v3f4(startPoint), plane);
 			float endDist = signedDistanceToPlane(v3f4(endPoint), plane);
 			bool startInside = startDist > 0.f, endInside = endDist > 0.f;
-			if (startInside && endInside) { out->pts[out->n++] = endPoint; }
-			else if (startInside) { out->pts[out->n++] = clipAgainstPlane(startPoint, endPoint, startDist, endDist); }
+			if (startInside && endInside) { PP(*out, out->n++) = endPoint; }
+			else if (startInside) { PP(*out, out->n++) = clipAgainstPlane(startPoint, endPoint, startDist, endDist); }
 			else if (!startInside && endInside)
 			{
-				out->pts[out->n++] = clipAgainstPlane(startPoint, endPoint, startDist, endDist);
-				out->pts[out->n++] = endPoint;
+				PP(*out, out->n++) = clipAgainstPlane(startPoint, endPoint, startDist, endDist);
+				PP(*out, out->n++) = endPoint;
 			}
 			startPoint = endPoint;
 		}
@@ -352,70 +358,75 @@ MI_DEV void sutherlandHodgman(Poly& input, const float4* clipPlanes, u32 numClip
 	}
 	if (clipIndex % 2 == 0)
 	{
-		for (u32 i = 0; i < input.n; ++i) output.pts[i] = input.pts[i];
+		for (u32 i = 0; i < input.n; ++i) PP(output, i) = PP(input, i);
 		output.n = input.n;
 	}
 }
-MI_DEV void findStableContactManifold(const float4* v, u32 nv, V3 normal, Man& m) // :56-146
+MI_DEV void findStableContactManifold(const Poly& poly, V3 normal, Man& m) // :56-146
 {
+	const u32 nv = poly.n;
+#define v(I_) PP(poly, I_)
 	if (nv > 4)
 	{
 		V3 searchDir = getTangent(normal);
-		float best = dot(searchDir, v3f4(v[0]));
+		float best = dot(searchDir, v3f4(v(0)));
 		u32 ri = 0;
-		for (u32 i = 1; i < nv; ++i) { float d = dot(searchDir, v3f4(v[i])); if (d > best) { ri = i; best = d; } }
-		m.p[0] = v[ri];
+		for (u32 i = 1; i < nv; ++i) { float d = dot(searchDir, v3f4(v(i))); if (d > best) { ri = i; best = d; } }
+		m.p[0] = v(ri);
 		best = 0.f; ri = 0;
-		for (u32 i = 0; i < nv; ++i) { float d = sqlen(v3f4(v[i]) - v3f4(m.p[0])); if (d > best) { ri = i; best = d; } }
-		m.p[1] = v[ri];
+		for (u32 i = 0; i < nv; ++i) { float d = sqlen(v3f4(v(i)) - v3f4(m.p[0])); if (d > best) { ri = i; best = d; } }
+		m.p[1] = v(ri);
 		best = 0.f; ri = 0;
 		for (u32 i = 0; i < nv; ++i)
 		{
-			V3 qa = v3f4(m.p[0]) - v3f4(v[i]), qb = v3f4(m.p[1]) - v3f4(v[i]);
+			V3 qa = v3f4(m.p[0]) - v3f4(v(i)), qb = v3f4(m.p[1]) - v3f4(v(i));
 			float area = 0.5f * dot(cross(qa, qb), normal);
 			if (area > best) { ri = i; best = area; }
 		}
-		m.p[2] = v[ri];
+		m.p[2] = v(ri);
 		best = 0.f; ri = 0;
 		for (u32 i = 0; i < nv; ++i)
 		{
-			V3 qa = v3f4(m.p[0]) - v3f4(v[i]), qb = v3f4(m.p[1]) - v3f4(v[i]), qc = v3f4(m.p[2]) - v3f4(v[i]);
+			V3 qa = v3f4(m.p[0]) - v3f4(v(i)), qb = v3f4(m.p[1]) - v3f4(v(i)), qc = v3f4(m.p[2]) - v3f4(v(i));
 			float area1 = 0.5f * dot(cross(qa, qb), normal);
 			float area2 = 0.5f * dot(cross(qb, qc), normal);
 			float area3 = 0.5f * dot(cross(qc, qa), normal);
 			float area = fmaxf(fmaxf(area1, area2), area3);
 			if (area > best) { ri = i; best = area; }
 		}
-		m.p[3] = v[ri];
+		m.p[3] = v(ri);
 		m.count = 4;
 	}
 	else
 	{
 		m.count = nv;
-		for (u32 i = 0; i < nv; ++i) m.p[i] = v[i];
+		for (u32 i = 0; i < nv; ++i) m.p[i] = v(i);
 	}
+#undef v
 }
-MI_DEV bool clipPointsAndBuildContact(Poly& polygon, const float4* clipPlanes, float4 referencePlane, Man& m) // :339-369
+MI_DEV bool clipPointsAndBuildContact(Poly& polygon, Poly& clipped, const float4* clipPlanes, float4 referencePlane, Man& m) // :339-369 (clipped: the second polygon's storage)
 {
-	Poly clipped; clipped.n = 0;
+	clipped.n = 0;
 	sutherlandHodgman(polygon, clipPlanes, 4, clipped);
 	if (clipped.n > 0)
 	{
 		for (u32 i = 0; i < clipped.n; ++i)
 		{
-			if (clipped.pts[i].w < 0.f)
+			float4 pt = PP(clipped, i);
+			if (pt.w < 0.f)
 			{
-				clipped.pts[i] = clipped.pts[clipped.n - 1];
+				PP(clipped, i) = PP(clipped, clipped.n - 1);
 				--clipped.n;
 				--i;
 			}
 			else
 			{
-				float d = clipped.pts[i].w;
-				clipped.pts[i].x += referencePlane.x * d; clipped.pts[i].y += referencePlane.y * d; clipped.pts[i].z += referencePlane.z * d;
+				float d = pt.w;
+				pt.x += referencePlane.x * d; pt.y += referencePlane.y * d; pt.z += referencePlane.z * d;
+				PP(clipped, i) = pt;
 			}
 		}
-		if (clipped.n > 0) { findStableContactManifold(clipped.pts, clipped.n, m.n, m); return true; }
+		if (clipped.n > 0) { findStableContactManifold(clipped, m.n, m); return true; }
 	}
 	return false;
 }
@@ -464,7 +475,7 @@ MI_DEV V3 obbSupport(const Obb& b, V3 dir) // collision_gjk.h:63-75
 }
 
 // OBB vs OBB — collision_narrow.cpp:1179-1527
-MI_DEV bool obbObb(const Obb& a, const Obb& b, Man& m)
+MI_DEV bool obbObb(const Obb& a, const Obb& b, Man& m, const PolyStore& store)
 {
 	V3 ax = a.q * v3(1.f, 0.f, 0.f), ay = a.q * v3(0.f, 1.f, 0.f), az = a.q * v3(0.f, 0.f, 1.f);
 	V3 bx = b.q * v3(1.f, 0.f, 0.f), by = b.q * v3(0.f, 1.f, 0.f), bz = b.q * v3(0.f, 0.f, 1.f);
@@ -533,7 +544,8 @@ MI_DEV bool obbObb(const Obb& a, const Obb& b, Man& m)
 	if (faceCollision)
 	{
 		V3 cpp[4], cpn[4], verts[4];
-		Poly polygon; polygon.n = 4;
+		Poly polygon; polygon.pts = store.a; polygon.stride = store.stride; polygon.n = 4;
+		Poly clipped; clipped.pts = store.b; clipped.stride = store.stride;
 		float4 plane;
 		if (!bFace)
 		{
@@ -553,9 +565,9 @@ MI_DEV bool obbObb(const Obb& a, const Obb& b, Man& m)
 		for (u32 i = 0; i < 4; ++i)
 		{
 			clipPlanes[i] = createPlane(cpp[i], cpn[i]);
-			polygon.pts[i] = make_float4(verts[i].x, verts[i].y, verts[i].z, -signedDistanceToPlane(verts[i], plane));
+			PP(polygon, i) = make_float4(verts[i].x, verts[i].y, verts[i].z, -signedDistanceToPlane(verts[i], plane));
 		}
-		if (!clipPointsAndBuildContact(polygon, clipPlanes, plane, m)) return false;
+		if (!clipPointsAndBuildContact(polygon, clipped, clipPlanes, plane, m)) return false;
 	}
 	else
 	{
@@ -901,14 +913,16 @@ MI_DEV void capsuleBoxFinish(V3 point, V3 normal, float depth, const Capsule& c,
 			V3 aabbNormal = -normal;
 			V3 refPoint = v3((aabbNormal.x < 0.f) ? a.lo.x : a.hi.x, (aabbNormal.y < 0.f) ? a.lo.y : a.hi.y, (aabbNormal.z < 0.f) ? a.lo.z : a.hi.z); // getAABBReferencePlane :291-299
 			float4 referencePlane = createPlane(refPoint, aabbNormal);
-			Poly polygon; polygon.n = 2;
+			float4 storeA[16], storeB[16];
+			Poly polygon; polygon.pts = storeA; polygon.stride = 1; polygon.n = 2;
+			Poly clipped; clipped.pts = storeB; clipped.stride = 1;
 			V3 pa = c.a + normal * c.r, pb = c.b + normal * c.r;
-			polygon.pts[0] = make_float4(pa.x, pa.y, pa.z, -signedDistanceToPlane(pa, referencePlane));
-			polygon.pts[1] = make_float4(pb.x, pb.y, pb.z, -signedDistanceToPlane(pb, referencePlane));
+			PP(polygon, 0) = make_float4(pa.x, pa.y, pa.z, -signedDistanceToPlane(pa, referencePlane));
+			PP(polygon, 1) = make_float4(pb.x, pb.y, pb.z, -signedDistanceToPlane(pb, referencePlane));
 			V3 aCenter = boxCenter(a);
 			getAABBClippingPlanes(boxRadius(a), aabbNormal, cpp, cpn);
 			for (u32 i = 0; i < 4; ++i) clipPlanes[i] = createPlane(cpp[i] + aCenter, cpn[i]);
-			clipPointsAndBuildContact(polygon, clipPlanes, referencePlane, m);
+			clipPointsAndBuildContact(polygon, clipped, clipPlanes, referencePlane, m);
 		}
 	}
 }
@@ -979,6 +993,9 @@ template <int GROUP>
 __global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(const u32* __restrict__ counters, const u32* __restrict__ keySorted, const u64* __restrict__ pairSorted,
 	const ColliderRec* __restrict__ colWorld, ManifoldRec* __restrict__ manifolds)
 {
+	// the box kernel's clipping polygons: two per lane, 16 points each, point i of lane l at [i * 64 + l] (conflict-free 16-byte accesses)
+	__shared__ float4 sPoly[GROUP == GROUP_BOX ? 2 * 16 * 64 : 1];
+	const PolyStore store = { sPoly + (GROUP == GROUP_BOX ? threadIdx.x : 0u), sPoly + (GROUP == GROUP_BOX ? 16u * 64u + threadIdx.x : 0u), 64u };
 	u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
 	if (GROUP == GROUP_BOX) { slot += counters[CTR_BUCKET_START + 22]; if (slot >= counters[CTR_BUCKET_START + 29]) return; }
 	if (slot >= counters[CTR_NUM_VALID]) return;
@@ -1011,7 +1028,7 @@ __global__ void __launch_bounds__(GROUP == GROUP_CLOSED ? 256 : 64) k_narrow(con
 		Obb oa;
 		if (key == 22) { Box b = asBox(A); oa.q = q4(0.f, 0.f, 0.f, 1.f); oa.c = boxCenter(b); oa.r = boxRadius(b); } // aabb -> obb (:1142-1148)
 		else oa = asObb(A);
-		hit = obbObb(oa, asObb(B), m);
+		hit = obbObb(oa, asObb(B), m, store);
 	}
 	writeManifold(manifolds, slot, m, hit, A, B, slot);
 }
@@ -1051,11 +1068,11 @@ __global__ void __launch_bounds__(256) k_gjk(u32* __restrict__ counters, const u
 	if (FAMILY == 1) j = listCap - 1u - j; // the hull pairs fill the list from its end
 	epaList[j] = slot;
 	float4* S = gjkSimplex + (size_t)j * 9;
-	const SupportPoint* P[4] = { &sx.a, &sx.b, &sx.c, &sx.d };
-	float f[36];
-	for (u32 i = 0; i < 4; ++i) { f[9 * i] = P[i]->a.x; f[9 * i + 1] = P[i]->a.y; f[9 * i + 2] = P[i]->a.z; f[9 * i + 3] = P[i]->b.x; f[9 * i + 4] = P[i]->b.y; f[9 * i + 5] = P[i]->b.z;
-		f[9 * i + 6] = P[i]->mk.x; f[9 * i + 7] = P[i]->mk.y; f[9 * i + 8] = P[i]->mk.z; }
-	for (u32 i = 0; i < 9; ++i) S[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+	// 4 support points x 9 floats, packed as 9 float4 (written out: an array of pointers to the four points goes through scratch memory)
+	const SupportPoint &p0 = sx.a, &p1 = sx.b, &p2 = sx.c, &p3 = sx.d;
+	S[0] = make_float4(p0.a.x, p0.a.y, p0.a.z, p0.b.x); S[1] = make_float4(p0.b.y, p0.b.z, p0.mk.x, p0.mk.y); S[2] = make_float4(p0.mk.z, p1.a.x, p1.a.y, p1.a.z);
+	S[3] = make_float4(p1.b.x, p1.b.y, p1.b.z, p1.mk.x); S[4] = make_float4(p1.mk.y, p1.mk.z, p2.a.x, p2.a.y); S[5] = make_float4(p2.a.z, p2.b.x, p2.b.y, p2.b.z);
+	S[6] = make_float4(p2.mk.x, p2.mk.y, p2.mk.z, p3.a.x); S[7] = make_float4(p3.a.y, p3.a.z, p3.b.x, p3.b.y); S[8] = make_float4(p3.b.z, p3.mk.x, p3.mk.y, p3.mk.z);
 }
 
 // Phase 2: EPA (EPA_GROUP lanes per hit = two hits per wave, polytopes in LDS) + face clipping (the group's first lane) for every GJK
@@ -1082,11 +1099,14 @@ __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) __attribute__((amdgp
 		SupShapes sh; Obb o;
 		gjkOperands<FAMILY>(key, A, B, hullInfo, hullVerts, sh, o);
 		const float4* S = gjkSimplex + (size_t)j * 9;
-		float f[36];
-		for (u32 i = 0; i < 9; ++i) { float4 v = S[i]; f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w; }
 		GjkSimplex sx; sx.numPoints = 4;
-		SupportPoint* P[4] = { &sx.a, &sx.b, &sx.c, &sx.d };
-		for (u32 i = 0; i < 4; ++i) { P[i]->a = v3(f[9 * i], f[9 * i + 1], f[9 * i + 2]); P[i]->b = v3(f[9 * i + 3], f[9 * i + 4], f[9 * i + 5]); P[i]->mk = v3(f[9 * i + 6], f[9 * i + 7], f[9 * i + 8]); }
+		{
+			const float4 s0 = S[0], s1 = S[1], s2 = S[2], s3 = S[3], s4 = S[4], s5 = S[5], s6 = S[6], s7 = S[7], s8 = S[8];
+			sx.a.a = v3(s0.x, s0.y, s0.z); sx.a.b = v3(s0.w, s1.x, s1.y); sx.a.mk = v3(s1.z, s1.w, s2.x);
+			sx.b.a = v3(s2.y, s2.z, s2.w); sx.b.b = v3(s3.x, s3.y, s3.z); sx.b.mk = v3(s3.w, s4.x, s4.y);
+			sx.c.a = v3(s4.z, s4.w, s5.x); sx.c.b = v3(s5.y, s5.z, s5.w); sx.c.mk = v3(s6.x, s6.y, s6.z);
+			sx.d.a = v3(s6.w, s7.x, s7.y); sx.d.b = v3(s7.z, s7.w, s8.x); sx.d.mk = v3(s8.y, s8.z, s8.w);
+		}
 		V3 point, normal; float depth;
 		epaWave<FAMILY>(e, lane, group * EPA_GROUP, sx, sh, point, normal, depth);
 		if (lane == 0)

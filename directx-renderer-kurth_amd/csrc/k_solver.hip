@@ -270,8 +270,10 @@ __global__ void __launch_bounds__(256) k_contact_init(const u32* __restrict__ co
 	rowShared[s] = make_float4(n.x, n.y, n.z, friction);
 	rowIds[s] = make_uint4(a, b, count, m);
 
-	for (u32 k = 0; k < count; ++k)
+#pragma unroll
+	for (u32 k = 0; k < MI_MAX_CONTACTS_PER_MANIFOLD; ++k) // (unrolled: man.p[k] stays in registers; a count-bounded loop indexes it dynamically, i.e. through scratch memory)
 	{
+		if (k >= count) break;
 		V3 point = v3f4(man.p[k]);
 		float depth = man.p[k].w;
 		V3 rA = point - posA, rB = point - posB;
