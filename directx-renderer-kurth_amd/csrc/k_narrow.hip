@@ -7,6 +7,7 @@
 #include "world.h"
 #include <rocprim/rocprim.hpp>
 #include "events.h"
+#include <cstddef>
 EventSink sinkOf(World& w);
 #include <algorithm>
 
@@ -318,7 +319,7 @@ MI_DEV bool boxBoxAxisAligned(Box a, Box b, Man& m) // :1074-1140
 // A clipping polygon: up to 16 points (x, y, z, penetration) — collision_narrow.cpp:148-152 — kept OUTSIDE the registers (its points are
 // indexed by loop counters): vertex i lives at pts[i * stride].  The box-box kernel gives every lane a column of an LDS array
 // (stride 64: a lane's accesses are LDS round trips, not scratch-memory ones through the vector memory path — its waves spent
-// 61 % of their cycles waiting for those); the lone lane that clips a capsule's segment behind EPA keeps a private array (stride 1).
+// 61 % of their cycles waiting for those); the lone lane that clips a capsule's segment behind EPA uses its finished polytope's LDS (stride 1).
 struct Poly { float4* pts; u32 stride; u32 n; };
 #define PP(P_, I_) (P_).pts[(I_) * (P_).stride]
 struct PolyStore { float4* a; float4* b; u32 stride; };
@@ -762,7 +763,7 @@ MI_DEV V3 barycentric(V3 a, V3 b, V3 c, V3 p) // math.cpp:1390-1408
 // ballot + popcount, so indices, tie-breaks and therefore results are those of the serial reference algorithm.
 // Support points are recomputed redundantly by every lane (wave-uniform values, no LDS traffic).
 // ---------------------------------------------------------------------------------------------------------------
-struct EpaWave
+struct alignas(16) EpaWave
 {
 	float pa[EPA_MAX_POINTS][3], pb[EPA_MAX_POINTS][3];          // support points on A and B; minkowski = a - b (bit-identical to the stored one)
 	float tnx[EPA_MAX_TRIANGLES], tny[EPA_MAX_TRIANGLES], tnz[EPA_MAX_TRIANGLES], tdist[EPA_MAX_TRIANGLES];
@@ -773,6 +774,7 @@ struct EpaWave
 	u32 refs[EPA_MAX_EDGES];
 	u32 border[EPA_MAX_BORDER], newEdgePerPoint[EPA_MAX_POINTS];
 };
+static_assert(offsetof(EpaWave, tnx) % 16 == 0 && sizeof(EpaWave) % 16 == 0 && 4 * sizeof(float) * EPA_MAX_TRIANGLES >= 2 * 16 * sizeof(float4), "the triangle arrays double as two 16-point clipping polygons (capsuleBoxFinish)");
 #define EPA_NONE32 0xFFFFu
 #define EPA_GROUP 32u                 // lanes per polytope (>= EPA_MAX_BORDER and EPA_MAX_POINTS: one lane per border edge / point)
 #define EPA_GROUP_MASK 0xFFFFFFFFu
@@ -899,7 +901,7 @@ __device__ void epaWave(EpaWave& e, u32 lane, u32 groupShift, const GjkSimplex& 
 }
 
 // Everything of intersection(capsule, aabb) after EPA — collision_narrow.cpp:723-768
-MI_DEV void capsuleBoxFinish(V3 point, V3 normal, float depth, const Capsule& c, const Box& a, Man& m)
+MI_DEV void capsuleBoxFinish(V3 point, V3 normal, float depth, const Capsule& c, const Box& a, Man& m, const PolyStore& store)
 {
 	m.n = normal; m.count = 1;
 	m.p[0] = make_float4(point.x, point.y, point.z, depth);
@@ -913,9 +915,8 @@ MI_DEV void capsuleBoxFinish(V3 point, V3 normal, float depth, const Capsule& c,
 			V3 aabbNormal = -normal;
 			V3 refPoint = v3((aabbNormal.x < 0.f) ? a.lo.x : a.hi.x, (aabbNormal.y < 0.f) ? a.lo.y : a.hi.y, (aabbNormal.z < 0.f) ? a.lo.z : a.hi.z); // getAABBReferencePlane :291-299
 			float4 referencePlane = createPlane(refPoint, aabbNormal);
-			float4 storeA[16], storeB[16];
-			Poly polygon; polygon.pts = storeA; polygon.stride = 1; polygon.n = 2;
-			Poly clipped; clipped.pts = storeB; clipped.stride = 1;
+			Poly polygon; polygon.pts = store.a; polygon.stride = store.stride; polygon.n = 2;
+			Poly clipped; clipped.pts = store.b; clipped.stride = store.stride;
 			V3 pa = c.a + normal * c.r, pb = c.b + normal * c.r;
 			PP(polygon, 0) = make_float4(pa.x, pa.y, pa.z, -signedDistanceToPlane(pa, referencePlane));
 			PP(polygon, 1) = make_float4(pb.x, pb.y, pb.z, -signedDistanceToPlane(pb, referencePlane));
@@ -1113,7 +1114,11 @@ __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) __attribute__((amdgp
 		{
 			Man m; m.count = 0; m.n = v3(0.f, 1.f, 0.f);
 			if (FAMILY == 1 || key == 14) { m.n = normal; m.count = 1; m.p[0] = make_float4(point.x, point.y, point.z, depth); } // :905-950; hull pairs
-			else capsuleBoxFinish(point, normal, depth, sh.tubeA, sh.box, m);
+			else
+			{
+				const PolyStore store = { (float4*)e.tnx, (float4*)e.tnx + 16, 1u }; // the finished polytope's triangle arrays (2 KB, 16-byte aligned) hold the two 16-point clipping polygons: LDS, not scratch
+				capsuleBoxFinish(point, normal, depth, sh.tubeA, sh.box, m, store);
+			}
 			if (key == 10 || key == 16) // back to world space (:779-787, :1032-1040)
 			{
 				m.n = o.q * m.n;
