@@ -401,7 +401,8 @@ MI_DEV void findStableContactManifold(const Poly& poly, V3 normal, Man& m) // :5
 	else
 	{
 		m.count = nv;
-		for (u32 i = 0; i < nv; ++i) m.p[i] = v(i);
+#pragma unroll
+		for (u32 i = 0; i < 4; ++i) if (i < nv) m.p[i] = v(i); // (static indices: a manifold's four points stay in registers)
 	}
 #undef v
 }
@@ -1122,8 +1123,10 @@ __global__ void __launch_bounds__(64 * EPA_WAVES_PER_BLOCK) __attribute__((amdgp
 			if (key == 10 || key == 16) // back to world space (:779-787, :1032-1040)
 			{
 				m.n = o.q * m.n;
-				for (u32 i = 0; i < m.count; ++i)
+#pragma unroll
+				for (u32 i = 0; i < 4; ++i)
 				{
+					if (i >= m.count) break;
 					V3 pt = o.q * (v3f4(m.p[i]) - o.c) + o.c;
 					m.p[i] = make_float4(pt.x, pt.y, pt.z, m.p[i].w);
 				}
