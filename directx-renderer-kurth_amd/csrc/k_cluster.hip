@@ -175,6 +175,7 @@ __global__ void __launch_bounds__(256) k_cl_clear(u32 nb1, u32* __restrict__ wsu
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < nb1) compLabel[i] = i;               // components of what the curve phases leave over: every body its own
 	if (i < 5u) counters[CTR_CL_LEFT + i] = 0;
+	if (i == 0u) counters[CTR_CL_SCRATCH] = 0;   // append cursor of the solve launch's row scratch
 	if (i < CL_MAX_TASKS) jointCount[i] = 0;
 	if (i < CL_MAX_PARTS * nb1) wsum[i] = 0;
 	if (i < nb1) phaseMask[i] = 0;
@@ -1556,7 +1557,7 @@ void launch_cluster_solve(World& w, u32 itBegin, u32 itEnd)
 	const size_t scratchContacts = std::min<size_t>(2 * w.pairCap, 512u * 1024u); // rows that fit neither the registers nor LDS (224 B each)
 	w.clRowScratch.ensure(scratchContacts * CLQ_ROW_FLOAT4S, w.stream);
 	if (w.lastError) return;
-	MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CL_SCRATCH, 0, sizeof(u32), w.stream));
+	if (itBegin) MI_CHECK(hipMemsetAsync(w.dCounters.p + CTR_CL_SCRATCH, 0, sizeof(u32), w.stream)); // (the step's first launch finds it cleared by k_cl_clear)
 	ClArgs A;
 	A.rowScratch = w.clRowScratch.p; A.scratchContacts = (u32)scratchContacts;
 	A.counters = w.dCounters.p; A.tasks = (const ClTask*)w.clTasks.p; A.bodyList = w.clBodyList.p; A.phaseMask = w.clPhaseMask.p; A.sharedSlot = w.clSharedSlot.p;
