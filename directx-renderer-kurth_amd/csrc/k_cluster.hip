@@ -1452,23 +1452,26 @@ void launch_cluster_build(World& w, u32 numPairs)
 	// Body order along the phases' curves.  Any order is correct, this one makes the clusters compact; bodies move a fraction of
 	// their size per step, so the order is refreshed every few steps only (four radix sorts of all bodies), at once when bodies were
 	// added and after a snapshot was taken or restored (so that a restored world and its original keep making the same choices).
-	const u32 P = CL_MAX_PARTS; // all curves, whatever the number of partition phases in use: that number adapts from step to step
+	const u32 P = CL_MAX_PARTS;
+	const u32 parts = w.useComponents ? std::min(w.clusterParts, CL_MAX_PARTS - 1u) : w.clusterParts; // curve phases (the component phase comes on top)
+	// the curves in use and the one behind them (phase p attributes what it leaves over along curve p + 1) are sorted; all of them the first
+	// time and when the body count changed, so that every rank array holds valid positions (each sort is ~80 us at 100 k bodies)
+	const u32 sortParts = (w.clusterSortBodies != nb) ? P : std::min(P, parts + 1u);
 	bool refresh = false; // this step re-sorts the bodies and re-cuts the chunks; the steps in between reuse the stored chunks
-	if (w.clusterSortDue || w.clusterSortAge >= w.clusterSortInterval || w.clusterSortBodies != nb)
+	if (w.clusterSortDue || w.clusterSortAge >= w.clusterSortInterval || w.clusterSortBodies != nb || w.clusterSortedParts < sortParts)
 	{
 		refresh = true;
 		ClShifts sh; u32 maxShift = 0;
 		for (u32 p = 0; p < CL_MAX_PARTS; ++p) for (u32 k = 0; k < 3; ++k) { sh.s[p][k] = w.clusterShift[p][k]; maxShift = std::max(maxShift, sh.s[p][k]); }
 		hipLaunchKernelGGL(k_cl_bbox, dim3(std::min<u32>(bgrid.x, 64u)), block, 0, w.stream, nb, w.cog.p, w.simMask.p, w.dCounters.p);
 		hipLaunchKernelGGL(k_cl_keys, bgrid, block, 0, w.stream, nb, P, sh, maxShift, w.cog.p, w.simMask.p, w.dCounters.p, w.clKeys.p, w.clVals.p);
-		for (u32 p = 0; p < P; ++p)
+		for (u32 p = 0; p < sortParts; ++p)
 			prim_sort_pairs_u32(w, w.clKeys.p + (size_t)p * nb, w.clKeysSorted.p + (size_t)p * nb, w.clVals.p + (size_t)p * nb, w.clSorted.p + (size_t)p * nb, nb, 30);
-		hipLaunchKernelGGL(k_cl_ranks, bgrid, block, 0, w.stream, nb, P, w.clSorted.p, w.clRank.p);
-		w.clusterSortDue = false; w.clusterSortAge = 0; w.clusterSortBodies = nb;
+		hipLaunchKernelGGL(k_cl_ranks, bgrid, block, 0, w.stream, nb, sortParts, w.clSorted.p, w.clRank.p);
+		w.clusterSortDue = false; w.clusterSortAge = 0; w.clusterSortBodies = nb; w.clusterSortedParts = sortParts; // (curves sorted by THIS refresh: one more phase in use than that forces the next refresh at once, so the order never depends on an older sort)
 	}
 	w.clusterSortAge++;
 	// tasks
-	const u32 parts = w.useComponents ? std::min(w.clusterParts, CL_MAX_PARTS - 1u) : w.clusterParts; // curve phases (the component phase comes on top)
 	u32 clearItems = std::max<u32>((u32)(CL_MAX_PARTS * nb1), totalKeys * CL_SUBCOUNTERS + 6u * CL_REMAIN_SUBS);
 	const bool withJoints = cluster_solves_joints(w);
 	const u32* rep = withJoints ? w.clRep.p : nullptr;

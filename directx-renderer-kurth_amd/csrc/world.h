@@ -196,7 +196,7 @@ struct World
 	bool lastStepCluster = false, backupVelocities = false;
 	u32 clusterPredictDiv = 4, clusterPollSleep = 1, clusterBlocksLimit = 0, clusterFailStreak = 0, clusterParts = 2, clusterTaskWeight = 64u * 1000u, clusterTaskWeightLater = 64u * 500u, clusterShift[CL_MAX_PARTS][3] = { { 0, 0, 0 }, { 13, 9, 15 }, { 27, 21, 31 }, { 7, 29, 5 } }; // MI_CLUSTER_PARTS / _TASK / _SHIFT
 	bool clusterPartsFixed = false;       // MI_CLUSTER_PARTS given: no adaptation
-	bool clusterSortDue = true; u32 clusterSortAge = 0, clusterSortInterval = 8, clusterSortBodies = 0; // body order along the curves: refreshed every few steps (MI_CLUSTER_SORT_INTERVAL)
+	bool clusterSortDue = true; u32 clusterSortAge = 0, clusterSortInterval = 8, clusterSortBodies = 0, clusterSortedParts = 0; // body order along the curves: refreshed every few steps (MI_CLUSTER_SORT_INTERVAL)
 	u32 clusterLdsBytes = 0, clusterBlocks = 0, clusterCooldown = 0;
 	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clEntry, clTaskCount, clTaskStart, clBodyList, clSharedSlot; // clEntry: the contact schedule of every task (at 4 x its first manifold position): manifold position | contact << 12
 	DevBuf<uint8_t> clTasks;
