@@ -1483,7 +1483,10 @@ void launch_cluster_build(World& w, u32 numPairs)
 	w.clCompLabel.ensure(nb1, w.stream); w.clLeftList.ensure(w.pairCap, w.stream);
 	if (w.lastError) return;
 	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.clJointCount.p, w.dCounters.p, w.clCompLabel.p);
-	u32* leftList = w.useComponents ? w.clLeftList.p : nullptr; const u32 leftCap = (u32)w.pairCap;
+	// A world whose curve phases left nothing over in the last step (ragdolls standing apart: every island interior to its task) skips
+	// the component phase's six launches; what the curves do leave over in this step then goes to the rest task, as without the
+	// component phase, and the next step runs the components again (World::countPreviousStep).
+	u32* leftList = (w.useComponents && !w.compIdle) ? w.clLeftList.p : nullptr; const u32 leftCap = (u32)w.pairCap;
 	const u32 firstFlags = withJoints ? CL_WEIGHT_ISLANDS : 0u; // (goes with the first phase's weight)
 	const u32 maxTasks = std::min<u32>(CL_MAX_TASKS / CL_TASKS_PER_PHASE, w.clusterBlocks) - std::min<u32>(8u, w.clusterBlocks / 8u); // per phase, with a margin for the chunks' rounding
 	w.clChunk.ensure((size_t)CL_MAX_PARTS * nb1, w.stream);

@@ -202,6 +202,7 @@ struct World
 	DevBuf<uint8_t> clTasks;
 	DevBuf<float4> clRowScratch;
 	DevBuf<u32> clCompLabel, clLeftList; bool useComponents = true; // the component phase (MI_CLUSTER_NO_COMPONENTS=1: curve phases + rest task only)
+	bool compIdle = false;                    // the last step's curve phases left nothing over (and its rest task was empty): this step skips the component phase's launches (what is left over goes to the rest task)
 	DevBuf<u32> clChunk; u32 clChunkParts = 0, clChunkJointVersion = ~0u; bool clChunkWithJoints = false, useChunkCache = true; u32 chunkHeadroomPercent = 10, chunkCachedPhases = CL_MAX_PARTS; // chunk of every body per phase, kept between re-sorts (MI_CLUSTER_NO_CHUNK_CACHE=1: the full partition pipeline every step)
 	// joints inside the cluster sweep: island representative per body (jointed bodies must share a task), the joints of all types in
 	// (type, colour) order {type | class << 8, index in the type's colour-sorted arrays, body a, body b}, and the per-step lists

@@ -733,6 +733,7 @@ void World::countPreviousStep()
 	// Partition phases of the next step: one more when the rest task is filling up (it has hard limits), one fewer when the last
 	// one found nothing to do (each costs a sort of the bodies).
 	if (had && lastStepCluster) clusterFailStreak = 0; // (a give-up never gets here: recoverFlow clears lastStepCluster)
+	compIdle = had && lastStepCluster && useComponents && hCounters[CTR_CL_LEFT] == 0u && hCounters[CTR_CL_PHASE_COUNT + CL_MAX_PARTS] == 0u;
 	if (had && lastStepCluster && (stats.numInternalSteps % 50u) == 0u && getenv("MI_CLUSTER_DEBUG"))
 		fprintf(stderr, "[mi_physics] step %u: component phase: %u manifolds left by the curve phases, %u tasks, weight %u, %u with ends in different components after the rounds, largest component sent to the rest task %u\n", stats.numInternalSteps,
 			hCounters[CTR_CL_LEFT], hCounters[CTR_CL_LEFT + 1], hCounters[CTR_CL_LEFT + 2], hCounters[CTR_CL_LEFT + 3], hCounters[CTR_CL_LEFT + 4]);
@@ -1227,6 +1228,7 @@ int mi_snapshot_save(mi_world* world, void* buffer, uint64_t capacity)
 	if (W->lastError) return W->lastError;
 	W->refreshCounters();     // the last step is counted now (and has had its say on the number of partition phases), not at the next step:
 	W->clusterSortDue = true; // the restored world orders its bodies at its first step: so does this one at its next ...
+	W->compIdle = false;      // ... and runs the component phase in it, as a world without a last step does (the step has been counted above)
 	if (!W->clusterPartsFixed) W->clusterParts = 3; // ... and both start from the default number of partition phases (without the component phase: with it the number is fixed)
 	W->clusterCooldown = 0; W->clusterFailStreak = 0; // ... with the cluster sweep on
 	if (!buffer || capacity < out.bytes.size()) { W->fail(MI_ERR_CAPACITY, "mi_snapshot_save: buffer too small (ask mi_snapshot_size)"); return MI_ERR_CAPACITY; }
