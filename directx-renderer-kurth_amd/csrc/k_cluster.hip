@@ -170,15 +170,16 @@ MI_DEV u32 clBid(u32 slot, u32 count, u32 round, u32 i) { return (((4u - count) 
 #define CL_SUBCOUNTERS 8u // a task's append cursor is split in 8 (by workgroup) so that ~650 returning atomics do not queue on one address
 
 // Everything the assignment accumulates into, cleared in one launch.
-__global__ void __launch_bounds__(256) k_cl_clear(u32 nb1, u32* __restrict__ wsum, u32* __restrict__ phaseMask, u32* __restrict__ taskCount, u32* __restrict__ jointCount, u32* __restrict__ counters, u32* __restrict__ compLabel)
+__global__ void __launch_bounds__(256) k_cl_clear(u32 nb1, u32* __restrict__ wsum, u32* __restrict__ phaseMask, u32* __restrict__ taskCount, u32* __restrict__ jointCount, u32* __restrict__ counters, u32* __restrict__ compLabel,
+	const u32* __restrict__ jointBodyMask, u32 keepJointLists)
 {
 	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < nb1) compLabel[i] = i;               // components of what the curve phases leave over: every body its own
 	if (i < 5u) counters[CTR_CL_LEFT + i] = 0;
 	if (i == 0u) counters[CTR_CL_SCRATCH] = 0;   // append cursor of the solve launch's row scratch
-	if (i < CL_MAX_TASKS) jointCount[i] = 0;
+	if (i < CL_MAX_TASKS && !keepJointLists) jointCount[i] = 0; // (between two refreshes the joints' tasks do not change: their lists are kept, see launch_cluster_build)
 	if (i < CL_MAX_PARTS * nb1) wsum[i] = 0;
-	if (i < nb1) phaseMask[i] = 0;
+	if (i < nb1) phaseMask[i] = (keepJointLists && jointBodyMask) ? jointBodyMask[i] : 0u; // (kept joint lists: their bodies' first-phase bit, which the joint assignment sets otherwise)
 	if (i < CL_MAX_PHASES * CL_MAX_TASKS * CL_SUBCOUNTERS + 6u * CL_REMAIN_SUBS) taskCount[i] = 0; // (+ the split 'still unassigned' counters behind the task counters)
 	if (i < 7u) counters[CTR_CL_STATUS + i] = 0;  // status, shared bodies, manifolds per phase
 	if (i < 6u) counters[CTR_CL_REMAIN + i] = 0;
@@ -1482,7 +1483,6 @@ void launch_cluster_build(World& w, u32 numPairs)
 	if (w.lastError) return;
 	w.clCompLabel.ensure(nb1, w.stream); w.clLeftList.ensure(w.pairCap, w.stream);
 	if (w.lastError) return;
-	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.clJointCount.p, w.dCounters.p, w.clCompLabel.p);
 	// A world whose curve phases left nothing over in the last step (ragdolls standing apart: every island interior to its task) skips
 	// the component phase's six launches; what the curves do leave over in this step then goes to the rest task, as without the
 	// component phase, and the next step runs the components again (World::countPreviousStep).
@@ -1492,6 +1492,11 @@ void launch_cluster_build(World& w, u32 numPairs)
 	w.clChunk.ensure((size_t)CL_MAX_PARTS * nb1, w.stream);
 	if (w.lastError) return;
 	if (!w.useChunkCache || w.clChunkParts < parts || w.clChunkJointVersion != w.jointVersion || w.clChunkWithJoints != withJoints) refresh = true;
+	// The joints' tasks follow their islands' chunks, which change at a refresh only: in between, the task lists of the joints (task,
+	// position, counts, the scattered list) are kept as the refresh step built them — two launches less per step for a ragdoll world.
+	const bool keepJointLists = !refresh && nj != 0u && w.clJointListsValid;
+	hipLaunchKernelGGL(k_cl_clear, dim3((clearItems + 255) / 256), block, 0, w.stream, (u32)nb1, w.clWsum.p, w.clPhaseMask.p, w.clTaskCount.p, w.clJointCount.p, w.dCounters.p, w.clCompLabel.p,
+		nj ? w.clJointBodyMask.p : (const u32*)nullptr, keepJointLists ? 1u : 0u);
 	if (refresh)
 	{
 		// (with the cache on, the chunks are cut 4 % short: the pile may grow until the next refresh)
@@ -1516,7 +1521,7 @@ void launch_cluster_build(World& w, u32 numPairs)
 		const u32 cached = std::min(parts, w.chunkCachedPhases);
 		hipLaunchKernelGGL(k_cl_assign_cached, mgrid, block, 0, w.stream, w.dCounters.p, nb, parts, cached, withJoints ? 1u : 0u, w.actIds.p, w.clChunk.p,
 			w.clRank.p + (size_t)std::min(cached, CL_MAX_PARTS - 1) * nb1, w.clWsum.p + (size_t)std::min(cached, CL_MAX_PARTS - 1) * nb1, w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p, leftList, leftCap);
-		if (nj) hipLaunchKernelGGL(k_cl_joint_assign_cached, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clChunk.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p);
+		if (nj && !keepJointLists) hipLaunchKernelGGL(k_cl_joint_assign_cached, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTable.p, w.clChunk.p, w.clJointTask.p, w.clJointPos.p, w.clJointCount.p, w.clPhaseMask.p);
 		for (u32 p = cached; p < parts; ++p) // the later phases: the per-step pipeline on what is left
 		{
 			u32* wsum = w.clWsum.p + (size_t)p * nb1; u32* wsumNext = w.clWsum.p + (size_t)std::min(p + 1, CL_MAX_PARTS - 1) * nb1;
@@ -1535,7 +1540,8 @@ void launch_cluster_build(World& w, u32 numPairs)
 			w.clTaskKey.p, w.clTaskPos.p, w.clTaskCount.p, w.clPhaseMask.p);
 	}
 	hipLaunchKernelGGL(k_cl_offsets, dim3(1), dim3(1024), 0, w.stream, w.dCounters.p, parts, w.clTaskCount.p, w.clTaskStart.p, nj ? w.clJointCount.p : (u32*)nullptr, nj ? w.clJointStart.p : (u32*)nullptr);
-	if (nj) hipLaunchKernelGGL(k_cl_joint_scatter, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTask.p, w.clJointPos.p, w.clJointStart.p, w.clJointList.p);
+	if (nj && !keepJointLists) hipLaunchKernelGGL(k_cl_joint_scatter, dim3((nj + 255) / 256), block, 0, w.stream, nj, w.clJointTask.p, w.clJointPos.p, w.clJointStart.p, w.clJointList.p);
+	w.clJointListsValid = nj != 0u && w.useChunkCache;
 	hipLaunchKernelGGL(k_cl_scatter, mgrid, block, 0, w.stream, w.dCounters.p, w.clTaskKey.p, w.clTaskPos.p, w.clTaskStart.p, w.clPre.p);
 	hipLaunchKernelGGL(k_cl_color, dim3(w.clusterBlocks), dim3(CL_LANES), clColorLdsBytes(), w.stream, w.dCounters.p, nb, w.clTaskStart.p, w.clPre.p, w.actIds.p,
 		w.clPhaseMask.p, (ClTask*)w.clTasks.p, w.clBodyList.p, w.mOrder.p, w.mKeySorted.p, w.clLocal.p, w.clEntry.p, w.clSharedSlot.p,

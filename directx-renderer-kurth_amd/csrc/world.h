@@ -201,6 +201,7 @@ struct World
 	DevBuf<u32> clKeys, clKeysSorted, clVals, clSorted, clRank, clWsum, clCum, clPhaseMask, clTaskKey, clTaskPos, clPre, clLocal, clEntry, clTaskCount, clTaskStart, clBodyList, clSharedSlot; // clEntry: the contact schedule of every task (at 4 x its first manifold position): manifold position | contact << 12
 	DevBuf<uint8_t> clTasks;
 	DevBuf<float4> clRowScratch;
+	DevBuf<u32> clJointBodyMask; bool clJointListsValid = false; // per body: 1 if a joint of the sweep touches it (phase-0 bit of its phase mask); the joints' task lists of the last refresh are still good
 	DevBuf<u32> clCompLabel, clLeftList; bool useComponents = true; // the component phase (MI_CLUSTER_NO_COMPONENTS=1: curve phases + rest task only)
 	bool compIdle = false;                    // the last step's curve phases left nothing over (and its rest task was empty): this step skips the component phase's launches (what is left over goes to the rest task)
 	DevBuf<u32> clChunk; u32 clChunkParts = 0, clChunkJointVersion = ~0u; bool clChunkWithJoints = false, useChunkCache = true; u32 chunkHeadroomPercent = 10, chunkCachedPhases = CL_MAX_PARTS; // chunk of every body per phase, kept between re-sorts (MI_CLUSTER_NO_CHUNK_CACHE=1: the full partition pipeline every step)

@@ -462,6 +462,10 @@ void World::uploadJoints()
 		clNumJoints = (u32)table.size(); clNumJointClasses = numClasses;
 		clJointsInCluster = clNumJoints > 0 && numClasses <= CL_MAX_JOINT_CLASSES;
 		if (getenv("MI_CLUSTER_DEBUG")) fprintf(stderr, "[mi_physics] joints: %u in %u levels -> %s\n", clNumJoints, numClasses, clJointsInCluster ? "inside the cluster sweep" : "own launches");
+		std::vector<u32> jointBody(n + 1, 0u);
+		for (const uint4& e : table) { if (e.z < n) jointBody[e.z] = 1u; if (e.w < n) jointBody[e.w] = 1u; }
+		clJointBodyMask.ensure(n + 1, stream); clJointListsValid = false;
+		MI_CHECK(hipMemcpyAsync(clJointBodyMask.p, jointBody.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, stream));
 		clRep.ensure(n + 1, stream); clJointTable.ensure(std::max<size_t>(table.size(), 1), stream);
 		MI_CHECK(hipMemcpyAsync(clRep.p, rep.data(), sizeof(u32) * (n + 1), hipMemcpyHostToDevice, stream));
 		if (!table.empty()) MI_CHECK(hipMemcpyAsync(clJointTable.p, table.data(), sizeof(uint4) * table.size(), hipMemcpyHostToDevice, stream));
