@@ -46,7 +46,8 @@ World::World(int dev) : device(dev)
 	dCounters.ensure(CTR_WORDS, stream);
 	if (dCounters.p) MI_CHECK(hipMemsetAsync(dCounters.p, 0, CTR_WORDS * sizeof(u32), stream));
 	stageEvents.resize(STAGE_RING * 6);
-	for (auto& e : stageEvents) MI_CHECK(hipEventCreate(&e));
+	// (device-scope events: a stage's time stamp needs no system-scope fence, and the host reads the counters from pinned memory behind an event it waits for)
+	for (auto& e : stageEvents) MI_CHECK(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
 	MI_CHECK(hipEventCreateWithFlags(&countersEvent, hipEventDisableTiming));
 	// The launch-per-colour sweep (the fallback solver) as plain launches: a hipGraph of its ~600 kernel nodes has to be re-instantiated
 	// whenever the number of colours changes (58 times in 260 steps of config 3, tens of ms each: 25 ms/step against 3 ms/step).
